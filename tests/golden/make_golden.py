@@ -1,0 +1,222 @@
+"""
+Golden-vector generator.  Runs ONLY in the build container, where the read-only
+reference checkout lives at /root/reference; its outputs (``*.npz`` / ``*.json``
+in this directory) are committed and are what travels to the GPU box.
+
+It imports the reference package (with dummy GUI modules),
+feeds it the deterministic inputs of ``tests/cases.py`` and stores what the
+reference returns.  No reference source text is copied: fixtures hold inputs
+and expected outputs only.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import cases  # noqa: E402
+
+
+def load_reference():
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, n):
+            return _Dummy()
+
+        def __call__(self, *a, **k):
+            return _Dummy()
+
+    def stub(name):
+        m = types.ModuleType(name)
+        m.__getattr__ = lambda n: type(n, (_Dummy,), {})
+        m.__all__ = []
+        m.__path__ = []
+        sys.modules[name] = m
+        if "." in name:
+            parent, child = name.rsplit(".", 1)
+            setattr(sys.modules[parent], child, m)
+
+    for n in ["OpenGL", "OpenGL.GL", "OpenGL.GLU", "OpenGL.GL.shaders", "pyopengltk",
+              "tkinter", "tkinter.ttk", "tkinter.colorchooser", "tkinter.filedialog"]:
+        stub(n)
+    sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True
+    import bspy
+    return bspy
+
+
+def reference_tables(bspy):
+    """The reference's own golden tables (tests/bspy_test.py:15-564) and the
+    Utah teapot data tables (examples/teapot.py:4-346), captured as data."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_bspy_test", "/root/reference/tests/bspy_test.py")
+    t = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(t)
+    out = {
+        "truthCurve": np.array(t.truthCurve, np.float64),
+        "truthSurface": np.array(t.truthSurface, np.float64),
+        "curve_knots0": np.array(t.myCurve.knots[0], np.float64),
+        "curve_coefs": np.ascontiguousarray(t.myCurve.coefs, np.float64),
+        "surface_knots0": np.array(t.mySurface.knots[0], np.float64),
+        "surface_knots1": np.array(t.mySurface.knots[1], np.float64),
+        "surface_coefs": np.ascontiguousarray(t.mySurface.coefs, np.float64),
+    }
+    # test_derivative's cross-check target: differentiate().evaluate(u) (tests/bspy_test.py:702-709)
+    d = t.myCurve.differentiate()
+    out["curve_differentiate_eval"] = np.array([d.evaluate(u) for u in out["truthCurve"][:, 0]])
+    # test_curvature pin: gaussian curvature of mySurface at (0.25, 0.5) (tests/bspy_test.py:699-700)
+    out["surface_jacobian_025_05"] = t.mySurface.jacobian([0.25, 0.5])
+    spec = importlib.util.spec_from_file_location("ref_teapot", "/root/reference/examples/teapot.py")
+    tp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    out["teapot_patch_index"] = np.array([p[1:] for p in tp.teapotPatches], np.int32)
+    out["teapot_vertices"] = np.array(tp.teapotVertices, np.float64)
+    names = [p[0] for p in tp.teapotPatches]
+    # oracle output of every teapot patch on a 16x16 broadcast grid (fp32, cfg4 shape)
+    knots = np.array((0, 0, 0, 0, 1, 1, 1, 1), np.float32)
+    g = np.linspace(0, 1, 16, dtype=np.float32)
+    grids = []
+    for p in tp.teapotPatches:
+        c = np.empty((3, 4, 4), np.float32)
+        for i in range(4):
+            for j in range(4):
+                v = p[4 * i + j + 1] - 1
+                c[0, i, j] = tp.teapotVertices[v][0]
+                c[1, i, j] = tp.teapotVertices[v][2]
+                c[2, i, j] = tp.teapotVertices[v][1]
+        s = bspy.Spline(2, 3, (4, 4), (4, 4), (knots, knots), c)
+        grids.append(np.stack(s(g[:, None], g[None, :])))
+    out["teapot_grid16"] = np.stack(grids).astype(np.float32)
+    return out, names
+
+
+def run_case(bspy, c):
+    s = bspy.Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    out = {}
+    for w in c.wrts:
+        r = s.derivative(list(w), *c.points) if any(w) else s.evaluate(*c.points)
+        r = np.stack(r) if isinstance(r, tuple) else np.asarray(r)[None, :]
+        out["wrt_" + "_".join(map(str, w))] = r
+    if c.jacobian:
+        jac = np.empty((c.n, c.nDep, c.nInd), c.coefs.dtype)
+        for i in range(c.n):
+            jac[i] = s.jacobian([p[i] for p in c.points])
+        out["jac"] = jac
+    return out
+
+
+def api_semantics(bspy):
+    """Shapes, dtypes, return types and error strings of the public wrappers
+    (spline.py:46-76, :720-770, :904-949; _spline_evaluation.py:109-164)."""
+    rec = {}
+    k = [0, 0, 0, 0, .3, .3, .7, 1, 1, 1, 1]
+    s = bspy.Spline(1, 2, [4], [7], [k], np.arange(14.0).reshape(2, 7))
+    rec["span_at_knots"] = [int(bspy.Spline.bspline_values(None, np.array(k), 4, u)[0]) for u in (0.0, 0.3, 0.7, 1.0)]
+
+    def err(f):
+        try:
+            f()
+        except Exception as e:  # noqa: BLE001
+            return [type(e).__name__, str(e)]
+        return None
+
+    rec["err_outside_scalar"] = err(lambda: s.evaluate([1.5]))
+    rec["err_outside_batch"] = err(lambda: s(np.array([0.1, 0.2, -0.25, 3.0])))
+    rec["err_arity"] = err(lambda: s.evaluate([0.1, 0.2]))
+    rec["err_outside_deriv"] = err(lambda: s.derivative([1], [-0.5]))
+    s2 = bspy.Spline(2, 3, [3, 4], [4, 5], [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]],
+                     np.arange(60.0).reshape(3, 4, 5))
+    rec["err_outside_batch2"] = err(lambda: s2(np.array([0.1, 0.2, 0.3]), np.array([0.5, 1.25, 7.0])))
+    rec["err_arity2"] = err(lambda: s2.evaluate([0.1]))
+    rec["err_ctor"] = {
+        "nInd": err(lambda: bspy.Spline(-1, 1, [], [], [], [])),
+        "order": err(lambda: bspy.Spline(1, 1, [4, 4], [4], [k], [[0, 1, 2, 3]])),
+        "nCoef": err(lambda: bspy.Spline(1, 1, [4], [4, 4], [k], [[0, 1, 2, 3]])),
+        "nknots": err(lambda: bspy.Spline(1, 1, [4], [4], [k], [[0.0, 1, 2, 3]])),
+        "knots_len": err(lambda: bspy.Spline(1, 1, [4], [4], [k, k], [[0.0, 1, 2, 3]])),
+        "knot_order": err(lambda: bspy.Spline(1, 1, [4], [4], [[0, 0, 0.5, 0.2, 1, 1, 1, 1]], [[0.0, 1, 2, 3]])),
+        "knot_mult": err(lambda: bspy.Spline(1, 1, [4], [5], [[0, 0, 0, 0, 0, 1, 1, 1, 1.0]], [[0.0, 1, 2, 3, 4]])),
+        "coefs_len": err(lambda: bspy.Spline(1, 2, [4], [4], [[0, 0, 0, 0, 1, 1, 1, 1.0]], [[0.0, 1, 2]])),
+    }
+    # return types / shapes
+    r = s.evaluate([0.25])
+    rec["scalar_list_shape"] = [list(r.shape), str(r.dtype), [float(x) for x in r]]
+    r = s.evaluate(0.25)
+    rec["scalar_shape"] = [list(r.shape), str(r.dtype), [float(x) for x in r]]
+    r = s2(0.25, 0.5)
+    rec["scalar2_shape"] = [list(r.shape), str(r.dtype), [float(x) for x in r]]
+    r = s2([0.25, 0.5])
+    rec["scalar2_list_shape"] = [list(r.shape), str(r.dtype), [float(x) for x in r]]
+    r = s2(np.array([0.25, 0.5]))
+    rec["scalar2_ndarray_shape"] = [list(r.shape), str(r.dtype), [float(x) for x in r]]
+    r = s(np.array([0.25, 0.5, 0.75]))
+    rec["batch_type"] = [type(r).__name__, len(r), list(r[0].shape), str(r[0].dtype)]
+    s1 = bspy.Spline(1, 1, [4], [7], [k], np.arange(7.0))
+    r = s1(np.array([0.25, 0.5, 0.75]))
+    rec["batch_ndep1_type"] = [type(r).__name__, list(r.shape), str(r.dtype), [float(x) for x in r]]
+    u = np.linspace(0, 1, 5)
+    r = s2(u[:, None], u[None, :])
+    rec["grid_type"] = [type(r).__name__, len(r), list(r[0].shape)]
+    rec["grid_values"] = [x.tolist() for x in r]
+    r = s2(u, 0.5)
+    rec["array_scalar_values"] = [x.tolist() for x in r]
+    r = s2.derivative([1, 0], u, 0.5)
+    rec["array_scalar_deriv_values"] = [x.tolist() for x in r]
+    rec["jacobian"] = s2.jacobian([0.25, 0.5]).tolist()
+    rec["tangent_space"] = s2.tangent_space([0.25, 0.5]).tolist()
+    rec["domain"] = s2.domain().tolist()
+    rec["nan_scalar"] = [float(x) for x in s.evaluate([float("nan")])]
+    # flat "list of points" coefficient form (spline.py:72-73)
+    flat = np.arange(60.0).reshape(20, 3)
+    s3 = bspy.Spline(2, 3, [3, 4], [4, 5], s2.knots, flat)
+    rec["flat_coefs"] = np.ascontiguousarray(s3.coefs).tolist()
+    # per-dependent-variable list form with transposed blocks (spline.py:75)
+    per = [np.arange(20.0).reshape(5, 4) + 100 * d for d in range(3)]
+    s4 = bspy.Spline(2, 3, [3, 4], [4, 5], s2.knots, per)
+    rec["perdep_coefs"] = np.ascontiguousarray(s4.coefs).tolist()
+    # nInd == 0
+    s0 = bspy.Spline(0, 2, [], [], [], [1.5, 2.5])
+    rec["nind0_eval"] = np.asarray(s0.evaluate()).tolist()
+    rec["nind0_deriv"] = np.asarray(s0.derivative([])).tolist()
+    # derivativeOrder >= order gives exact zeros (tests/bspy_test.py:759-761)
+    rec["zero_derivative"] = s.derivative([4], [0.5]).tolist()
+    return rec
+
+
+def main():
+    bspy = load_reference()
+    tables, names = reference_tables(bspy)
+    np.savez_compressed(os.path.join(HERE, "reference_tables.npz"), **tables)
+    with open(os.path.join(HERE, "teapot_names.json"), "w") as f:
+        json.dump(names, f)
+
+    parity = {}
+    for c in cases.parity_cases():
+        for k, v in run_case(bspy, c).items():
+            parity[f"{c.name}/{k}"] = v
+        print("case", c.name, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "parity.npz"), **parity)
+
+    ix, basis = [], []
+    for (knots, order, u, deriv, taylor, knot) in cases.basis_cases():
+        i, b = bspy.Spline.bspline_values(knot, knots, order, u, deriv, taylor)
+        ix.append(int(i))
+        row = np.zeros(9, np.float64)
+        row[:order] = b
+        basis.append(row)
+    np.savez_compressed(os.path.join(HERE, "basis.npz"), ix=np.array(ix, np.int32), basis=np.array(basis))
+
+    with open(os.path.join(HERE, "api_semantics.json"), "w") as f:
+        json.dump(api_semantics(bspy), f, indent=1)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
