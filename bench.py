@@ -1,0 +1,183 @@
+"""
+bench.py - BASELINE metric: M evals/s on the 10 M-point bicubic (order 4x4, nCoef 64x64,
+nDep 3, fp64) surface (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (Spline.evaluate: span search + Cox-de Boor recursion
++ tensor-product contraction, fused in one HIP kernel) over one batch of 10 M synthetic
+(u, v) points per GPU, inputs and outputs resident in HBM.  Multi-GPU: the point batch is
+sharded, one process per GPU, no data-path collective in the timed region (weak scaling:
+10 M points per rank); the all-gather-inclusive figure is measured separately and reported
+under "with_allgather".
+
+Prints ONE JSON line (rank 0).  roofline.achieved uses the ALGORITHMIC bytes of
+SURVEY.md 8(d): 40 B per eval (2 x 8 B in + 3 x 8 B out) against 8 TB/s HBM3E.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+N_POINTS = 10_000_000
+BYTES_PER_EVAL = {"evaluate": 40, "derivative": 40, "jacobian": 64}
+
+
+def cpu_baseline(order, ncoef, knots, coefs, sample):
+    """The C oracle (a port of the reference's algorithm, 1 core) on a bounded sample of
+    the same workload, plus the reference-structured Python loop on a smaller one."""
+    import oracle
+    rng = np.random.default_rng(12345)
+    uv = rng.random((2, sample))
+    oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [uv[0][:1000], uv[1][:1000]])   # load + warm
+    t0 = time.perf_counter()
+    _, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [uv[0], uv[1]])
+    t1 = time.perf_counter()
+    assert bad == -1
+    npy = 20_000
+    t2 = time.perf_counter()
+    oracle.py_batch(order, ncoef, knots, coefs, [0, 0], [uv[0][:npy], uv[1][:npy]])
+    t3 = time.perf_counter()
+    return {
+        "value": round(sample / (t1 - t0) / 1e6, 4), "unit": "M evals/s", "cores": 1, "kind": "port",
+        "sample": f"{sample} of the 10M random (u,v) points, C oracle (oracle/bspline_oracle.c), one thread",
+        "python_reference_structured": {"value": round(npy / (t3 - t2) / 1e6, 5), "unit": "M evals/s", "cores": 1,
+                                        "sample": f"{npy} points, per-point Python/NumPy loop (oracle.py_batch)"},
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian"], default="evaluate")
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import cases
+    import bspy_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dist = None
+    torch.cuda.set_device(local_rank)
+    bspy_amd.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(2)
+    n = args.points
+    rng = np.random.default_rng(1000 + rank)            # every rank owns a different shard
+    uv = rng.random((2, n))
+    dev = torch.device("cuda", local_rank)
+    u = torch.as_tensor(uv[0], device=dev)
+    v = torch.as_tensor(uv[1], device=dev)
+    tables = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt, device=local_rank)
+    rows = ndep * nind if args.op == "jacobian" else ndep
+    out = torch.empty((ndep, nind, n) if args.op == "jacobian" else (ndep, n), dtype=torch.float64, device=dev)
+    wrt = [1, 1] if args.op == "derivative" else None
+
+    def step():
+        if args.op == "jacobian":
+            tables.jacobian_device([u, v], out=out, check=False)
+        else:
+            tables.evaluate_device([u, v], wrt, out=out, check=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    tables.domain_status()                                # the in-kernel domain check found nothing
+    elapsed = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps        # average launch duration, HIP events on the launch stream
+    if dist is not None:
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+
+    # gather-inclusive variant (results replicated on every rank), outside the headline timing
+    gathered = None
+    if dist is not None:
+        full = torch.empty((world, rows, n), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            step()
+            dist.all_gather_into_tensor(full, out.view(rows, n))
+        barrier()
+        g0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            dist.all_gather_into_tensor(full, out.view(rows, n))
+        barrier()
+        g1 = time.perf_counter()
+        tt = torch.tensor([g1 - g0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        gsec = float(tt[0]) / args.steps
+        gathered = {"value": round(world * n / gsec / 1e6, 1), "unit": "M evals/s", "ms_per_step": round(gsec * 1e3, 4),
+                    "allgather_bytes_per_rank_in": (world - 1) * rows * n * 8,
+                    "xgmi_in_GBs_per_gpu": round((world - 1) * rows * n * 8 / gsec / 1e9, 1)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n / (elapsed / args.steps) / 1e6
+        bpe = BYTES_PER_EVAL[args.op]
+        achieved = bpe * n / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "M evals/sec on 10M-point bicubic (p=3x3) surface",
+            "value": round(value, 1), "unit": "M evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: bicubic surface order 4x4, nCoef 64x64, nDep 3, fp64, "
+                                   f"Spline.{args.op} on {n} uniform-random (u,v) per GPU",
+                       "points_per_gpu": n, "op": args.op, "sharding": "point batch sharded per rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "eval_fixed<double,2,4,LDS>" if args.op != "jacobian" else "jac_fixed<double,2,4,LDS>",
+                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_eval": bpe},
+        }
+        if gathered is not None:
+            res["with_allgather"] = gathered
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(order, ncoef, knots, coefs, args.cpu_sample)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,243 @@
+"""
+Module-function form of the evaluation path, mirroring ``bspy/_spline_evaluation.py``
+of the reference (same names, argument meaning and error behaviour) so callers that
+bind to the module functions (``bspy/spline_block.py:197,224``) can bind to these:
+
+    bspline_values(knot, knots, splineOrder, u, derivativeOrder=0, taylorCoefs=False)   :4-27
+    derivative(self, with_respect_to, uvw)                                              :109-133
+    domain(self)                                                                        :135-138
+    evaluate(self, uvw)                                                                 :140-164
+    jacobian(self, uvw)                                                                 :205-213
+
+``self`` is any object with the reference ``Spline``'s attributes (``nInd, nDep, order,
+nCoef, knots, coefs``) - a ``bspy_amd.Spline`` or the reference's own ``Spline``.
+
+Every function computes on the GPU through libbspy_amd.so (span search, Cox-de Boor
+recursion and window contraction are HIP kernels); there is no CPU path.  Single-point
+calls are batches of one.  ``evaluate_batch`` / ``jacobian_batch`` are the batched
+entry points behind ``Spline.evaluate`` / ``Spline.derivative`` (reference:
+``np.frompyfunc`` loop, bspy/spline.py:757-770, :936-949).
+"""
+import zlib
+
+import numpy as np
+
+from . import _native as nv
+from .device_spline import DeviceSpline, _is_torch, bspline_values_batch, get_device
+
+
+def compute_dtype(self):
+    """float32 only when every knot vector AND the coefficients are float32 (the
+    reference's all-fp32 path, e.g. examples/teapot.py); otherwise float64.  Mixed
+    fp32/fp64 inputs are computed in fp64, which is at least as accurate as the
+    reference's fp32 basis (bspy/_spline_evaluation.py:5)."""
+    if self.coefs.dtype == np.float32 and all(np.asarray(k).dtype == np.float32 for k in self.knots):
+        return np.dtype(np.float32)
+    return np.dtype(np.float64)
+
+
+def _fingerprint(self):
+    h = zlib.adler32(np.ascontiguousarray(self.coefs).view(np.uint8).reshape(-1))
+    for k in self.knots:
+        h = zlib.adler32(np.ascontiguousarray(k).view(np.uint8).reshape(-1), h)
+    return (h, self.coefs.shape, str(self.coefs.dtype), tuple(len(k) for k in self.knots))
+
+
+def device_tables(self, device=None):
+    """The DeviceSpline of ``self`` on ``device`` (created on first use, cached on the
+    object).  The reference's attributes are mutable (bspy/_spline_fitting.py:529-540
+    writes coefs in place), so the cache is validated against a checksum of knots and
+    coefs on every call and re-uploaded when they changed."""
+    device = get_device() if device is None else int(device)
+    cache = self.__dict__.setdefault("_bsk_cache", {})
+    dt = compute_dtype(self)
+    fp = _fingerprint(self)
+    entry = cache.get(device)
+    if entry is not None and entry[1] == fp:
+        return entry[0]
+    if entry is not None and entry[1][1:] == fp[1:] and entry[0].dtype == dt:
+        entry[0].update(self.knots, self.coefs)
+        cache[device] = (entry[0], fp)
+        return entry[0]
+    if entry is not None:
+        entry[0].close()
+    tables = DeviceSpline(self.order, self.nCoef, self.knots, self.coefs, dt, device)
+    cache[device] = (tables, fp)
+    return tables
+
+
+def bspline_values(knot, knots, splineOrder, u, derivativeOrder=0, taylorCoefs=False):
+    """Reference bspy/_spline_evaluation.py:4-27.  Scalar ``u`` returns
+    ``(knot, basis[splineOrder])``; an array ``u`` (extension) returns
+    ``(knot[N], basis[N, splineOrder])``."""
+    knots = np.asarray(knots)
+    scalar = np.ndim(u) == 0
+    ix, basis = bspline_values_batch(knots, splineOrder, np.atleast_1d(u), derivativeOrder, taylorCoefs, knot)
+    if knots.dtype != basis.dtype and np.issubdtype(knots.dtype, np.floating):
+        basis = basis.astype(knots.dtype)
+    if scalar:
+        return int(ix[0]), basis[0]
+    return ix, basis
+
+
+def domain(self):
+    """Reference bspy/_spline_evaluation.py:135-138."""
+    dom = [[self.knots[i][self.order[i] - 1], self.knots[i][self.nCoef[i]]] for i in range(self.nInd)]
+    return np.array(dom)
+
+
+def _point(self, with_respect_to, uvw):
+    uvw = np.atleast_1d(uvw)
+    if len(uvw) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
+    if with_respect_to is not None and len(with_respect_to) != self.nInd:
+        raise ValueError(f"Incorrect number of derivative orders: {len(with_respect_to)}")
+    tables = device_tables(self)
+    try:
+        out = tables.evaluate([uvw[i:i + 1] for i in range(self.nInd)], with_respect_to)
+    except nv.DomainError:
+        raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
+    return out[:, 0]
+
+
+def evaluate(self, uvw):
+    """Reference bspy/_spline_evaluation.py:140-164 (one point)."""
+    return _point(self, None, uvw)
+
+
+def derivative(self, with_respect_to, uvw):
+    """Reference bspy/_spline_evaluation.py:109-133 (one point)."""
+    return _point(self, [int(w) for w in with_respect_to], uvw)
+
+
+def jacobian(self, uvw):
+    """Reference bspy/_spline_evaluation.py:205-213: (nDep, nInd) at one point, in the
+    coefficients' dtype.  One fused kernel instead of nInd derivative calls."""
+    uvw = np.atleast_1d(uvw)
+    if len(uvw) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
+    tables = device_tables(self)
+    try:
+        out = tables.jacobian([uvw[i:i + 1] for i in range(self.nInd)])
+    except nv.DomainError:
+        raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
+    return out[:, :, 0].astype(self.coefs.dtype, copy=False)
+
+
+# --------------------------------------------------------------------------------------
+# batched entry points
+# --------------------------------------------------------------------------------------
+
+def _grid_axes(arrays, shape):
+    """If the broadcast of ``arrays`` is a tensor-product grid (every array varies along
+    exactly one axis of ``shape``, all of them different), return for each array the axis
+    it varies along (None for a single value); else None."""
+    axes = []
+    for a in arrays:
+        nd = a.ndim
+        varying = [len(shape) - nd + k for k in range(nd) if a.shape[k] != 1]
+        if len(varying) > 1:
+            return None
+        axes.append(varying[0] if varying else None)
+    used = [ax for ax in axes if ax is not None]
+    if len(set(used)) != len(used):
+        return None
+    # every non-trivial axis of the result must be driven by exactly one variable
+    for k, n in enumerate(shape):
+        if n != 1 and k not in used:
+            return None
+    return axes
+
+
+_GRID_MIN_POINTS = 4096
+
+
+def _domain_message(arrays, shape, index):
+    # the reference reports the first offending point in broadcast (C) order, as the
+    # tuple of Python floats np.frompyfunc handed to the scalar routine
+    pt = [float(np.broadcast_to(a, shape).reshape(-1)[index]) for a in arrays]
+    return f"Spline evaluation outside domain: {np.atleast_1d(pt)}"
+
+
+def evaluate_batch(self, with_respect_to, uvw, device=None, check=True):
+    """Batched evaluate/derivative: ``uvw`` = nInd broadcastable arrays (NumPy path,
+    results returned as NumPy) or CUDA torch tensors (device path, results stay on the
+    GPU).  Returns an array of shape ``(nDep, *broadcast_shape)``."""
+    if len(uvw) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
+    wrt = None if with_respect_to is None else [int(w) for w in with_respect_to]
+    if wrt is not None and len(wrt) != self.nInd:
+        raise ValueError(f"Incorrect number of derivative orders: {len(wrt)}")
+    if any(_is_torch(a) for a in uvw):
+        import torch
+        dev = next(a for a in uvw if _is_torch(a) and a.is_cuda).device
+        ts = [a if _is_torch(a) else torch.as_tensor(np.asarray(a), device=dev) for a in uvw]
+        ts = torch.broadcast_tensors(*[t.to(dev) for t in ts])
+        shape = tuple(ts[0].shape)
+        tables = device_tables(self, dev.index)
+        try:
+            out = tables.evaluate_device(ts, wrt, check=check)
+        except nv.DomainError as e:
+            cpu = [t.reshape(-1)[e.index].item() for t in ts]
+            raise ValueError(f"Spline evaluation outside domain: {np.atleast_1d(cpu)}") from None
+        return out.view((self.nDep, *shape))
+
+    dt = compute_dtype(self)
+    arrays = [np.asarray(a) for a in uvw]
+    shape = np.broadcast_shapes(*[a.shape for a in arrays])
+    total = int(np.prod(shape, dtype=np.int64))
+    tables = device_tables(self, device)
+    axes = _grid_axes(arrays, shape) if (self.nInd >= 2 and total >= _GRID_MIN_POINTS) else None
+    try:
+        if axes is not None:
+            # tensor-product broadcast (e.g. s(u[:, None], v[None, :])): per-variable basis
+            # rows once, then one contraction per grid point
+            grid = tables.evaluate_grid([a.reshape(-1) for a in arrays], wrt)      # (nDep, n_0, ..., n_{nInd-1})
+            # result axis k is driven by variable var_of[k]; variables with one value drop out
+            order_axes = [iv for iv in range(self.nInd) if axes[iv] is not None]
+            grid = grid.reshape((self.nDep, *[arrays[iv].size for iv in order_axes]))
+            perm = sorted(range(len(order_axes)), key=lambda j: axes[order_axes[j]])
+            grid = np.transpose(grid, (0, *[p + 1 for p in perm]))
+            return np.ascontiguousarray(grid).reshape((self.nDep, *shape))
+        flat = [np.ascontiguousarray(np.broadcast_to(a, shape), dt).reshape(-1) for a in arrays]
+        out = tables.evaluate(flat, wrt)
+    except nv.DomainError as e:
+        index = e.index
+        if axes is not None:
+            # the grid kernel numbers points in variable order; the reference reports the
+            # first offender in broadcast (C) order of the result
+            dom = domain(self)
+            bad = np.zeros(shape, bool)
+            for iv, a in enumerate(arrays):
+                bad |= np.broadcast_to((a < dom[iv][0]) | (a > dom[iv][1]), shape)
+            index = int(np.argmax(bad.reshape(-1)))
+        raise ValueError(_domain_message(arrays, shape, index)) from None
+    return out.reshape((self.nDep, *shape))
+
+
+def jacobian_batch(self, uvw, device=None, check=True):
+    """Batched jacobian (extension; the reference's is single-point): returns
+    ``(nDep, nInd, *broadcast_shape)``."""
+    if len(uvw) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
+    if any(_is_torch(a) for a in uvw):
+        import torch
+        dev = next(a for a in uvw if _is_torch(a) and a.is_cuda).device
+        ts = torch.broadcast_tensors(*[(a if _is_torch(a) else torch.as_tensor(np.asarray(a))).to(dev) for a in uvw])
+        shape = tuple(ts[0].shape)
+        tables = device_tables(self, dev.index)
+        try:
+            out = tables.jacobian_device(ts, check=check)
+        except nv.DomainError as e:
+            cpu = [t.reshape(-1)[e.index].item() for t in ts]
+            raise ValueError(f"Spline evaluation outside domain: {np.atleast_1d(cpu)}") from None
+        return out.view((self.nDep, self.nInd, *shape))
+    dt = compute_dtype(self)
+    arrays = [np.asarray(a) for a in uvw]
+    shape = np.broadcast_shapes(*[a.shape for a in arrays])
+    flat = [np.ascontiguousarray(np.broadcast_to(a, shape), dt).reshape(-1) for a in arrays]
+    try:
+        out = device_tables(self, device).jacobian(flat)
+    except nv.DomainError as e:
+        raise ValueError(_domain_message(arrays, shape, e.index)) from None
+    return out.reshape((self.nDep, self.nInd, *shape))

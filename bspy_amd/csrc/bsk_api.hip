@@ -1,0 +1,686 @@
+// C ABI of libbspy_amd.so (see include/bspy_amd.h).  Host side: table construction,
+// kernel selection and launch, host<->device staging for BSK_HOST buffers.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bsk_kernels.hpp"
+
+using namespace bsk;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static bsk_status fail(bsk_status st, const std::string &msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct bsk_spline_s {
+    bsk_dtype dtype;
+    int device;
+    int nInd, nDep;
+    int order[MAXI], ncoef[MAXI];
+    bool same_order;         // every variable has the same order
+    size_t esize;
+    Desc<float> d32;
+    Desc<double> d64;
+    void *tab = nullptr;     // device axis table
+    void *coef = nullptr;    // device coefficients
+    unsigned long long *bad = nullptr;  // device out-of-domain record
+    int num_cu = 256;
+    size_t lds_max = 160 * 1024;
+    DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
+};
+
+template <typename T>
+static Desc<T> &desc_of(bsk_spline s);
+template <>
+Desc<float> &desc_of<float>(bsk_spline s) { return s->d32; }
+template <>
+Desc<double> &desc_of<double>(bsk_spline s) { return s->d64; }
+
+static int ceil_log2(int x)
+{
+    int s = 0;
+    while ((1 << s) < x) ++s;
+    return s;
+}
+
+// Host construction of the axis table of one variable (layout: see Desc).
+template <typename T>
+static void build_axis_table(const T *knots, int order, int nk, std::vector<T> &tab)
+{
+    const size_t base = tab.size();
+    tab.resize(base + (size_t)order * nk, T(0));
+    for (int i = 0; i < nk; ++i) tab[base + i] = knots[i];
+    for (int dgr = 1; dgr < order; ++dgr)
+        for (int i = 0; i + dgr < nk; ++i) {
+            const T den = knots[i + dgr] - knots[i];     // formed in T, as the reference does
+            tab[base + (size_t)dgr * nk + i] = den > T(0) ? T(1.0 / (double)den) : T(0);
+        }
+}
+
+template <typename T>
+static bsk_status upload_tables(bsk_spline s, const void *const *knots, const void *coefs)
+{
+    Desc<T> &d = desc_of<T>(s);
+    std::vector<T> tab;
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        d.off[iv] = (int)tab.size();
+        const T *k = static_cast<const T *>(knots[iv]);
+        build_axis_table<T>(k, s->order[iv], d.nk[iv], tab);
+        d.lo[iv] = k[s->order[iv] - 1];          // domain: reference _spline_evaluation.py:135-138
+        d.hi[iv] = k[s->ncoef[iv]];
+    }
+    if ((int)tab.size() != d.tab_len) return fail(BSK_ERR_INVALID, "internal: axis table size changed");
+    HIPCHK(hipSetDevice(s->device));
+    if (d.tab_len) HIPCHK(hipMemcpy(s->tab, tab.data(), sizeof(T) * tab.size(), hipMemcpyHostToDevice));
+    if (d.coef_len) HIPCHK(hipMemcpy(s->coef, coefs, sizeof(T) * (size_t)d.coef_len, hipMemcpyHostToDevice));
+    return BSK_OK;
+}
+
+template <typename T>
+static bsk_status init_desc(bsk_spline s)
+{
+    Desc<T> &d = desc_of<T>(s);
+    memset(&d, 0, sizeof(d));
+    d.nInd = s->nInd;
+    d.nDep = s->nDep;
+    long long clen = 1;
+    long long tlen = 0;
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        d.order[iv] = s->order[iv];
+        d.ncoef[iv] = s->ncoef[iv];
+        d.nk[iv] = s->order[iv] + s->ncoef[iv];
+        d.steps[iv] = ceil_log2(s->ncoef[iv] - s->order[iv] + 1);
+        tlen += (long long)s->order[iv] * d.nk[iv];
+        clen *= s->ncoef[iv];
+    }
+    d.cstride[s->nInd] = 1;
+    for (int iv = s->nInd - 1; iv >= 0; --iv) {
+        const long long st = (long long)d.cstride[iv + 1] * s->ncoef[iv];
+        if (st * std::max(1, s->nDep) > 0x7fffffffLL) return fail(BSK_ERR_UNSUPPORTED, "coefficient table exceeds 2^31 elements");
+        d.cstride[iv] = (int)st;
+    }
+    if (tlen > 0x7fffffffLL) return fail(BSK_ERR_UNSUPPORTED, "knot table too large");
+    d.tab_len = (int)tlen;
+    d.coef_len = (int)(clen * s->nDep);
+    return BSK_OK;
+}
+
+extern "C" int bsk_version(void) { return BSK_VERSION; }
+extern "C" const char *bsk_last_error(void) { return g_err.c_str(); }
+
+extern "C" bsk_status bsk_device_count(int *count)
+{
+    if (!count) return fail(BSK_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(BSK_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, int nDep, const int *order,
+                                        const int *nCoef, const void *const *knots, const void *coefs,
+                                        bsk_spline *out)
+{
+    if (!out) return fail(BSK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dtype != BSK_F32 && dtype != BSK_F64) return fail(BSK_ERR_INVALID, "dtype must be BSK_F32 or BSK_F64");
+    if (nInd < 1 || nInd > MAXI) return fail(BSK_ERR_UNSUPPORTED, "nInd must be in [1, BSK_MAX_NIND]");
+    if (nDep < 1) return fail(BSK_ERR_INVALID, "nDep must be >= 1");
+    if (!order || !nCoef || !knots || !coefs) return fail(BSK_ERR_INVALID, "NULL argument");
+    for (int iv = 0; iv < nInd; ++iv) {
+        if (order[iv] < 1 || order[iv] > MAXO) return fail(BSK_ERR_UNSUPPORTED, "order must be in [1, BSK_MAX_ORDER]");
+        if (nCoef[iv] < order[iv]) return fail(BSK_ERR_INVALID, "nCoef < order");
+        if (!knots[iv]) return fail(BSK_ERR_INVALID, "NULL knots pointer");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BSK_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return fail(BSK_ERR_INVALID, "device index out of range");
+
+    bsk_spline s = new bsk_spline_s();
+    s->dtype = dtype;
+    s->device = device;
+    s->nInd = nInd;
+    s->nDep = nDep;
+    s->esize = dtype == BSK_F32 ? 4 : 8;
+    s->same_order = true;
+    for (int iv = 0; iv < nInd; ++iv) {
+        s->order[iv] = order[iv];
+        s->ncoef[iv] = nCoef[iv];
+        if (order[iv] != order[0]) s->same_order = false;
+    }
+    bsk_status st = dtype == BSK_F32 ? init_desc<float>(s) : init_desc<double>(s);
+    if (st != BSK_OK) { delete s; return st; }
+    const int tab_len = dtype == BSK_F32 ? s->d32.tab_len : s->d64.tab_len;
+    const int coef_len = dtype == BSK_F32 ? s->d32.coef_len : s->d64.coef_len;
+
+    auto cleanup = [&]() {
+        if (s->tab) (void)hipFree(s->tab);
+        if (s->coef) (void)hipFree(s->coef);
+        if (s->bad) (void)hipFree(s->bad);
+        delete s;
+    };
+#define HIPCHK_C(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            cleanup();                                                                        \
+            return fail(BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                     \
+    } while (0)
+    HIPCHK_C(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK_C(hipGetDeviceProperties(&prop, device));
+    s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s->lds_max = std::min<size_t>(160 * 1024, prop.maxSharedMemoryPerMultiProcessor > 0
+                                                  ? (size_t)prop.maxSharedMemoryPerMultiProcessor
+                                                  : (size_t)64 * 1024);
+    HIPCHK_C(hipMalloc(&s->tab, std::max<size_t>(16, s->esize * (size_t)tab_len)));
+    HIPCHK_C(hipMalloc(&s->coef, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+    HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
+    HIPCHK_C(hipMemset(s->bad, 0xff, sizeof(unsigned long long)));
+#undef HIPCHK_C
+    st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
+    if (st != BSK_OK) { cleanup(); return st; }
+    *out = s;
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_spline_update(bsk_spline s, const void *const *knots, const void *coefs)
+{
+    if (!s || !knots || !coefs) return fail(BSK_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    return s->dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
+}
+
+extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
+{
+    if (!s) return BSK_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (s->tab) (void)hipFree(s->tab);
+    if (s->coef) (void)hipFree(s->coef);
+    if (s->bad) (void)hipFree(s->bad);
+    s->in_ws.release();
+    s->out_ws.release();
+    s->aux_ws.release();
+    delete s;
+    return BSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// launch plans
+// ------------------------------------------------------------------------------------
+struct Plan {
+    bool lds_coefs;
+    size_t lds_bytes;
+    int block, grid;
+};
+
+// LDS budget: the whole axis table always, the coefficient table when both fit in one
+// CU's 160 KiB.  Workgroups are persistent: as many as fit per CU by LDS and by the
+// 2048-lane limit, each striding over the batch.
+template <typename T>
+static Plan make_plan(bsk_spline s, long long n)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    Plan p;
+    const size_t tab_b = sizeof(T) * (size_t)((d.tab_len + 1) & ~1);
+    const size_t coef_b = sizeof(T) * (size_t)d.coef_len;
+    const size_t limit = s->lds_max - 1024;   // keep clear of the hard limit
+    p.lds_coefs = tab_b + coef_b <= limit;
+    p.lds_bytes = tab_b + (p.lds_coefs ? coef_b : 0);
+    int per_cu;   // workgroups per CU
+    if (p.lds_bytes > limit / 2) { p.block = 1024; per_cu = 1; }
+    else if (p.lds_bytes > limit / 4) { p.block = 1024; per_cu = 2; }
+    else if (p.lds_bytes > limit / 8) { p.block = 512; per_cu = 4; }
+    else { p.block = 256; per_cu = 8; }
+    long long blocks = (n + p.block - 1) / p.block;
+    p.grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * per_cu));
+    return p;
+}
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+template <typename T, int NIND, int O>
+static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T> &prm, long long n, T *out,
+                                    long long ostride, const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    if (p.lds_coefs) {
+        HIPCHK(allow_lds(eval_fixed<T, NIND, O, true>, p.lds_bytes));
+        hipLaunchKernelGGL((eval_fixed<T, NIND, O, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, ostride, w, s->bad);
+    } else {
+        HIPCHK(allow_lds(eval_fixed<T, NIND, O, false>, p.lds_bytes));
+        hipLaunchKernelGGL((eval_fixed<T, NIND, O, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, ostride, w, s->bad);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
+template <typename T, int NIND, int O>
+static bsk_status launch_jac_fixed(bsk_spline s, const Plan &p, const Params<T> &prm, long long n, T *out,
+                                   hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    if (p.lds_coefs) {
+        HIPCHK(allow_lds(jac_fixed<T, NIND, O, true>, p.lds_bytes));
+        hipLaunchKernelGGL((jac_fixed<T, NIND, O, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, s->bad);
+    } else {
+        HIPCHK(allow_lds(jac_fixed<T, NIND, O, false>, p.lds_bytes));
+        hipLaunchKernelGGL((jac_fixed<T, NIND, O, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, s->bad);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
+template <typename T>
+static bsk_status launch_eval_generic(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                      const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const int block = 256;
+    const long long blocks = (n + block - 1) / block;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
+    hipLaunchKernelGGL((eval_generic<T>), dim3(grid), dim3(block), 0, st, d, static_cast<const T *>(s->tab),
+                       static_cast<const T *>(s->coef), prm, n, out, ostride, w, s->bad);
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
+// Fast-path coverage: nInd 1..3, one common order 1..6.
+static bool has_fixed_path(bsk_spline s)
+{
+    return s->same_order && s->nInd >= 1 && s->nInd <= 3 && s->order[0] >= 1 && s->order[0] <= 6;
+}
+
+#define BSK_ORDER_SWITCH(NIND, CALL)                        \
+    switch (s->order[0]) {                                  \
+        case 1: return CALL(NIND, 1);                       \
+        case 2: return CALL(NIND, 2);                       \
+        case 3: return CALL(NIND, 3);                       \
+        case 4: return CALL(NIND, 4);                       \
+        case 5: return CALL(NIND, 5);                       \
+        case 6: return CALL(NIND, 6);                       \
+        default: break;                                     \
+    }
+
+template <typename T>
+static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                const Wrt &w, hipStream_t st)
+{
+    if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s)) {
+        const Plan p = make_plan<T>(s, n);
+#define CALL_EVAL(NIND, O) launch_eval_fixed<T, NIND, O>(s, p, prm, n, out, ostride, w, st)
+        if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_EVAL) }
+        else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_EVAL) }
+        else { BSK_ORDER_SWITCH(3, CALL_EVAL) }
+#undef CALL_EVAL
+    }
+    return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
+}
+
+template <typename T>
+static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st)
+{
+    if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s)) {
+        const Plan p = make_plan<T>(s, n);
+#define CALL_JAC(NIND, O) launch_jac_fixed<T, NIND, O>(s, p, prm, n, out, st)
+        if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_JAC) }
+        else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_JAC) }
+        else { BSK_ORDER_SWITCH(3, CALL_JAC) }
+#undef CALL_JAC
+    }
+    // generic: nInd unit-derivative passes, as the reference does (_spline_evaluation.py:205-213)
+    for (int j = 0; j < s->nInd; ++j) {
+        Wrt w;
+        for (int iv = 0; iv < MAXI; ++iv) w.w[iv] = (iv == j);
+        bsk_status r = launch_eval_generic<T>(s, prm, n, out + (long long)j * n, (long long)s->nInd * n, w, st);
+        if (r != BSK_OK) return r;
+    }
+    return BSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// out-of-domain record
+// ------------------------------------------------------------------------------------
+static bsk_status read_bad(bsk_spline s, hipStream_t st, int64_t *first_bad)
+{
+    unsigned long long v = NO_BAD;
+    HIPCHK(hipMemcpyAsync(&v, s->bad, sizeof(v), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (v != NO_BAD) {
+        HIPCHK(hipMemsetAsync(s->bad, 0xff, sizeof(v), st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (first_bad) *first_bad = (int64_t)v;
+        return fail(BSK_ERR_DOMAIN, "parameter outside the spline's domain at flat index " + std::to_string(v));
+    }
+    if (first_bad) *first_bad = -1;
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_domain_status(bsk_spline s, void *stream, int64_t *first_bad)
+{
+    if (!s) return fail(BSK_ERR_INVALID, "NULL handle");
+    HIPCHK(hipSetDevice(s->device));
+    return read_bad(s, static_cast<hipStream_t>(stream), first_bad);
+}
+
+// ------------------------------------------------------------------------------------
+// evaluate / derivative / jacobian
+// ------------------------------------------------------------------------------------
+// BSK_HOST batches are processed in chunks so the staging buffers stay bounded.
+static constexpr long long HOST_CHUNK = 1ll << 24;
+
+template <typename T>
+static bsk_status run_points(bsk_spline s, bool jac, const int *wrt, const void *const *uvw, long long n, bsk_mem mem,
+                             void *out, hipStream_t st, int64_t *first_bad)
+{
+    Wrt w;
+    for (int iv = 0; iv < MAXI; ++iv) w.w[iv] = (wrt && iv < s->nInd) ? wrt[iv] : 0;
+    for (int iv = 0; iv < s->nInd; ++iv)
+        if (w.w[iv] < 0) return fail(BSK_ERR_INVALID, "negative derivative order");
+    const int outs = jac ? s->nDep * s->nInd : s->nDep;   // output rows per point
+    if (first_bad) *first_bad = -1;
+    if (n == 0) return BSK_OK;
+
+    if (mem == BSK_DEVICE) {
+        Params<T> prm;
+        for (int iv = 0; iv < MAXI; ++iv) prm.p[iv] = iv < s->nInd ? static_cast<const T *>(uvw[iv]) : nullptr;
+        return jac ? dispatch_jac<T>(s, prm, n, static_cast<T *>(out), st)
+                   : dispatch_eval<T>(s, prm, n, static_cast<T *>(out), n, w, st);
+    }
+
+    // host buffers: stage chunk by chunk
+    const long long chunk = std::min(n, HOST_CHUNK);
+    HIPCHK(s->in_ws.reserve(sizeof(T) * (size_t)chunk * s->nInd));
+    HIPCHK(s->out_ws.reserve(sizeof(T) * (size_t)chunk * outs));
+    T *din = static_cast<T *>(s->in_ws.p);
+    T *dout = static_cast<T *>(s->out_ws.p);
+    for (long long start = 0; start < n; start += chunk) {
+        const long long m = std::min(chunk, n - start);
+        Params<T> prm;
+        for (int iv = 0; iv < MAXI; ++iv) prm.p[iv] = nullptr;
+        for (int iv = 0; iv < s->nInd; ++iv) {
+            HIPCHK(hipMemcpyAsync(din + (size_t)iv * m, static_cast<const T *>(uvw[iv]) + start, sizeof(T) * (size_t)m,
+                                  hipMemcpyHostToDevice, st));
+            prm.p[iv] = din + (size_t)iv * m;
+        }
+        bsk_status r = jac ? dispatch_jac<T>(s, prm, m, dout, st) : dispatch_eval<T>(s, prm, m, dout, m, w, st);
+        if (r != BSK_OK) return r;
+        for (int row = 0; row < outs; ++row)
+            HIPCHK(hipMemcpyAsync(static_cast<T *>(out) + (size_t)row * n + start, dout + (size_t)row * m,
+                                  sizeof(T) * (size_t)m, hipMemcpyDeviceToHost, st));
+        int64_t bad = -1;
+        r = read_bad(s, st, &bad);     // also synchronises the chunk
+        if (r == BSK_ERR_DOMAIN) {
+            if (first_bad) *first_bad = start + bad;
+            return r;
+        }
+        if (r != BSK_OK) return r;
+    }
+    return BSK_OK;
+}
+
+static bsk_status check_call(bsk_spline s, const void *const *uvw, int64_t n, void *out)
+{
+    if (!s) return fail(BSK_ERR_INVALID, "NULL handle");
+    if (n < 0) return fail(BSK_ERR_INVALID, "negative point count");
+    if (n > 0) {
+        if (!uvw || !out) return fail(BSK_ERR_INVALID, "NULL buffer");
+        for (int iv = 0; iv < s->nInd; ++iv)
+            if (!uvw[iv]) return fail(BSK_ERR_INVALID, "NULL parameter pointer");
+    }
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_evaluate(bsk_spline s, const int *wrt, const void *const *uvw, int64_t n, bsk_mem mem,
+                                   void *out, void *stream, int64_t *first_bad)
+{
+    bsk_status r = check_call(s, uvw, n, out);
+    if (r != BSK_OK) return r;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32 ? run_points<float>(s, false, wrt, uvw, n, mem, out, st, first_bad)
+                               : run_points<double>(s, false, wrt, uvw, n, mem, out, st, first_bad);
+}
+
+extern "C" bsk_status bsk_jacobian(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem mem, void *out,
+                                   void *stream, int64_t *first_bad)
+{
+    bsk_status r = check_call(s, uvw, n, out);
+    if (r != BSK_OK) return r;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32 ? run_points<float>(s, true, nullptr, uvw, n, mem, out, st, first_bad)
+                               : run_points<double>(s, true, nullptr, uvw, n, mem, out, st, first_bad);
+}
+
+// ------------------------------------------------------------------------------------
+// tensor-product grid
+// ------------------------------------------------------------------------------------
+template <typename T>
+static bsk_status run_grid(bsk_spline s, const int *wrt, const void *const *grid, const int64_t *ngrid, bsk_mem mem,
+                           void *out, hipStream_t st, int64_t *first_bad)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    if (first_bad) *first_bad = -1;
+    GridDims g;
+    long long total = 1, npar = 0, nrow = 0;
+    for (int iv = 0; iv < MAXI; ++iv) { g.n[iv] = 1; g.goff[iv] = 0; g.roff[iv] = 0; }
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        if (ngrid[iv] < 0) return fail(BSK_ERR_INVALID, "negative grid size");
+        if (wrt && wrt[iv] < 0) return fail(BSK_ERR_INVALID, "negative derivative order");
+        g.n[iv] = ngrid[iv];
+        g.goff[iv] = npar;
+        g.roff[iv] = nrow;
+        npar += ngrid[iv];
+        nrow += ngrid[iv] * s->order[iv];
+        total *= ngrid[iv];
+    }
+    if (total == 0) return BSK_OK;
+
+    // aux workspace: [params T x npar (host mode only)] [rows T x nrow] [ix int x npar] [outside u8 x npar]
+    const size_t par_b = mem == BSK_HOST ? ((sizeof(T) * (size_t)npar + 15) & ~(size_t)15) : 0;
+    const size_t row_b = (sizeof(T) * (size_t)nrow + 15) & ~(size_t)15;
+    const size_t ix_b = (sizeof(int) * (size_t)npar + 15) & ~(size_t)15;
+    HIPCHK(s->aux_ws.reserve(par_b + row_b + ix_b + (size_t)npar + 16));
+    char *base = static_cast<char *>(s->aux_ws.p);
+    T *dpar = reinterpret_cast<T *>(base);
+    T *rows = reinterpret_cast<T *>(base + par_b);
+    int *ixs = reinterpret_cast<int *>(base + par_b + row_b);
+    unsigned char *outside = reinterpret_cast<unsigned char *>(base + par_b + row_b + ix_b);
+
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        const T *u = static_cast<const T *>(grid[iv]);
+        if (mem == BSK_HOST) {
+            HIPCHK(hipMemcpyAsync(dpar + g.goff[iv], u, sizeof(T) * (size_t)ngrid[iv], hipMemcpyHostToDevice, st));
+            u = dpar + g.goff[iv];
+        }
+        const int block = 256;
+        const int blocks = (int)((ngrid[iv] + block - 1) / block);
+        hipLaunchKernelGGL((basis_rows<T>), dim3(blocks), dim3(block), 0, st,
+                           static_cast<const T *>(s->tab) + d.off[iv], d.nk[iv], d.order[iv], d.ncoef[iv],
+                           d.steps[iv], u, (long long)ngrid[iv], wrt ? wrt[iv] : 0, 0, (const int *)nullptr,
+                           ixs + g.goff[iv], rows + g.roff[iv], d.lo[iv], d.hi[iv], outside + g.goff[iv]);
+        HIPCHK(hipGetLastError());
+    }
+
+    T *dout = static_cast<T *>(out);
+    if (mem == BSK_HOST) {
+        HIPCHK(s->out_ws.reserve(sizeof(T) * (size_t)total * s->nDep));
+        dout = static_cast<T *>(s->out_ws.p);
+    }
+    const T *coef = static_cast<const T *>(s->coef);
+    bool launched = false;
+    if (s->nInd == 2 && s->same_order && g.n[0] <= 65535) {
+        const int block = 256;
+        const int gx = (int)std::max<long long>(1, std::min<long long>((g.n[1] + block - 1) / block, 64));
+#define GRID_SURF(O)                                                                                           \
+    case O:                                                                                                    \
+        hipLaunchKernelGGL((grid_surface<T, O>), dim3(gx, (unsigned)g.n[0]), dim3(block), 0, st, d, coef, g,   \
+                           ixs, rows, outside, dout, s->bad);                                                  \
+        launched = true;                                                                                       \
+        break;
+        switch (s->order[0]) {
+            GRID_SURF(1) GRID_SURF(2) GRID_SURF(3) GRID_SURF(4) GRID_SURF(5) GRID_SURF(6)
+            default: break;
+        }
+#undef GRID_SURF
+    }
+    if (!launched) {
+        const int block = 256;
+        const long long blocks = (total + block - 1) / block;
+        const int gridx = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
+        hipLaunchKernelGGL((grid_generic<T>), dim3(gridx), dim3(block), 0, st, d, coef, g, ixs, rows, outside, total,
+                           dout, s->bad);
+    }
+    HIPCHK(hipGetLastError());
+    if (mem == BSK_HOST) {
+        HIPCHK(hipMemcpyAsync(out, dout, sizeof(T) * (size_t)total * s->nDep, hipMemcpyDeviceToHost, st));
+        return read_bad(s, st, first_bad);
+    }
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_evaluate_grid(bsk_spline s, const int *wrt, const void *const *grid, const int64_t *ngrid,
+                                        bsk_mem mem, void *out, void *stream, int64_t *first_bad)
+{
+    if (!s || !grid || !ngrid || !out) return fail(BSK_ERR_INVALID, "NULL argument");
+    for (int iv = 0; iv < s->nInd; ++iv)
+        if (!grid[iv] && ngrid[iv] > 0) return fail(BSK_ERR_INVALID, "NULL grid pointer");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32 ? run_grid<float>(s, wrt, grid, ngrid, mem, out, st, first_bad)
+                               : run_grid<double>(s, wrt, grid, ngrid, mem, out, st, first_bad);
+}
+
+// ------------------------------------------------------------------------------------
+// batched bspline_values
+// ------------------------------------------------------------------------------------
+template <typename T>
+static bsk_status run_basis(int device, const T *knots, int nknots, int order, const T *u, long long n, int deriv,
+                            int taylor, const int32_t *knot_in, int32_t *ix_out, T *basis_out)
+{
+    HIPCHK(hipSetDevice(device));
+    std::vector<T> tab;
+    build_axis_table<T>(knots, order, nknots, tab);
+    const int ncoef = nknots - order;
+    DevBuf dtab, du, dk, dix, db;
+    auto release = [&]() { dtab.release(); du.release(); dk.release(); dix.release(); db.release(); };
+#define HIPCHK_R(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            release();                                                                        \
+            return fail(BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                     \
+    } while (0)
+    HIPCHK_R(dtab.reserve(sizeof(T) * tab.size()));
+    HIPCHK_R(du.reserve(sizeof(T) * (size_t)n));
+    HIPCHK_R(dix.reserve(sizeof(int) * (size_t)n));
+    HIPCHK_R(db.reserve(sizeof(T) * (size_t)n * order));
+    HIPCHK_R(hipMemcpy(dtab.p, tab.data(), sizeof(T) * tab.size(), hipMemcpyHostToDevice));
+    HIPCHK_R(hipMemcpy(du.p, u, sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
+    if (knot_in) {
+        HIPCHK_R(dk.reserve(sizeof(int) * (size_t)n));
+        HIPCHK_R(hipMemcpy(dk.p, knot_in, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    const int block = 256;
+    const int blocks = (int)((n + block - 1) / block);
+    hipLaunchKernelGGL((basis_rows<T>), dim3(blocks), dim3(block), 0, 0, static_cast<const T *>(dtab.p), nknots, order,
+                       ncoef, ceil_log2(ncoef - order + 1), static_cast<const T *>(du.p), n, deriv, taylor,
+                       static_cast<const int *>(dk.p), static_cast<int *>(dix.p), static_cast<T *>(db.p), T(0), T(0),
+                       (unsigned char *)nullptr);
+    HIPCHK_R(hipGetLastError());
+    HIPCHK_R(hipMemcpy(ix_out, dix.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK_R(hipMemcpy(basis_out, db.p, sizeof(T) * (size_t)n * order, hipMemcpyDeviceToHost));
+#undef HIPCHK_R
+    release();
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void *knots, int nknots, int order,
+                                         const void *u, int64_t n, int derivative_order, int taylor_coefs,
+                                         const int32_t *knot_in, int32_t *ix_out, void *basis_out)
+{
+    if (!knots || !u || !ix_out || !basis_out) return fail(BSK_ERR_INVALID, "NULL argument");
+    if (order < 1 || order > MAXO) return fail(BSK_ERR_UNSUPPORTED, "order must be in [1, BSK_MAX_ORDER]");
+    if (nknots < 2 * order) return fail(BSK_ERR_INVALID, "need at least 2 * order knots");
+    if (derivative_order < 0) return fail(BSK_ERR_INVALID, "negative derivative order");
+    if (n < 0) return fail(BSK_ERR_INVALID, "negative count");
+    if (n == 0) return BSK_OK;
+    if (knot_in)
+        for (int64_t i = 0; i < n; ++i)
+            if (knot_in[i] < order || knot_in[i] > nknots - order)
+                return fail(BSK_ERR_INVALID, "explicit knot index outside [order, len(knots) - order]");
+    if (dtype == BSK_F32)
+        return run_basis<float>(device, static_cast<const float *>(knots), nknots, order, static_cast<const float *>(u),
+                                n, derivative_order, taylor_coefs, knot_in, ix_out, static_cast<float *>(basis_out));
+    if (dtype == BSK_F64)
+        return run_basis<double>(device, static_cast<const double *>(knots), nknots, order,
+                                 static_cast<const double *>(u), n, derivative_order, taylor_coefs, knot_in, ix_out,
+                                 static_cast<double *>(basis_out));
+    return fail(BSK_ERR_INVALID, "dtype must be BSK_F32 or BSK_F64");
+}

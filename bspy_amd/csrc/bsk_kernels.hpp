@@ -1,0 +1,326 @@
+// Kernels of libbspy_amd (gfx950).  One lane = one parameter point; the parameter batch
+// and the results stream through HBM fully coalesced (SoA), the spline's tables are
+// staged once per workgroup into LDS and the workgroups are persistent (grid-stride).
+#pragma once
+#include "bsk_device.hpp"
+
+namespace bsk {
+
+constexpr int BLOCK_MAX = 1024;
+
+// Copy the axis table (and, when it fits, the coefficient table) into LDS.
+template <typename T>
+__device__ __forceinline__ void stage_tables(T *stab, T *scoef, const T *__restrict__ gtab, int tab_len,
+                                             const T *__restrict__ gcoef, int coef_len, bool with_coefs)
+{
+    for (int i = threadIdx.x; i < tab_len; i += blockDim.x) stab[i] = gtab[i];
+    if (with_coefs)
+        for (int i = threadIdx.x; i < coef_len; i += blockDim.x) scoef[i] = gcoef[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------
+// evaluate / derivative, all variables of the same compile-time order O.
+//   LDSC: coefficient table staged in LDS (else gathered from global memory / L2).
+// out[d * ostride + n]
+// ---------------------------------------------------------------------------------
+template <typename T, int NIND, int O, bool LDSC>
+__global__ __launch_bounds__(BLOCK_MAX) void eval_fixed(const Desc<T> d, const T *__restrict__ gtab,
+                                                        const T *__restrict__ gcoef, const Params<T> prm,
+                                                        const long long N, T *__restrict__ out,
+                                                        const long long ostride, const Wrt wrt,
+                                                        unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *stab = reinterpret_cast<T *>(smem);
+    T *scoef = stab + ((d.tab_len + 1) & ~1);
+    stage_tables(stab, scoef, gtab, d.tab_len, gcoef, d.coef_len, LDSC);
+
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T b[NIND][O];
+        int base = 0;
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            const T u = prm.p[iv][n];
+            outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
+            const T *tab = stab + d.off[iv];
+            const int ix = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u);
+            basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
+            base += (ix - O) * d.cstride[iv + 1];
+        }
+        if (outside) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            T r;
+            if constexpr (LDSC) {
+                const T *c = scoef + dep * d.cstride[0] + base;
+                if constexpr (NIND == 1) r = contract1<T, O>(c, b[0]);
+                else if constexpr (NIND == 2) r = contract2<T, O>(c, d.cstride[1], b[0], b[1]);
+                else r = contract3<T, O>(c, d.cstride[1], d.cstride[2], b[0], b[1], b[2]);
+            } else {
+                const T *__restrict__ c = gcoef + dep * d.cstride[0] + base;
+                if constexpr (NIND == 1) r = contract1<T, O>(c, b[0]);
+                else if constexpr (NIND == 2) r = contract2<T, O>(c, d.cstride[1], b[0], b[1]);
+                else r = contract3<T, O>(c, d.cstride[1], d.cstride[2], b[0], b[1], b[2]);
+            }
+            out[dep * ostride + n] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// fused jacobian: every first partial derivative from one span search and one
+// recursion per variable, coefficients read once.  out[(dep * NIND + j) * N + n]
+// ---------------------------------------------------------------------------------
+template <typename T, int NIND, int O, bool LDSC>
+__global__ __launch_bounds__(BLOCK_MAX) void jac_fixed(const Desc<T> d, const T *__restrict__ gtab,
+                                                       const T *__restrict__ gcoef, const Params<T> prm,
+                                                       const long long N, T *__restrict__ out,
+                                                       unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *stab = reinterpret_cast<T *>(smem);
+    T *scoef = stab + ((d.tab_len + 1) & ~1);
+    stage_tables(stab, scoef, gtab, d.tab_len, gcoef, d.coef_len, LDSC);
+
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T b[NIND][O], db[NIND][O];
+        int base = 0;
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            const T u = prm.p[iv][n];
+            outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
+            const T *tab = stab + d.off[iv];
+            const int ix = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u);
+            basis_value_and_d1<T, O>(tab, d.nk[iv], ix, u, b[iv], db[iv]);
+            base += (ix - O) * d.cstride[iv + 1];
+        }
+        if (outside) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            const T *c = (LDSC ? (const T *)scoef : gcoef) + dep * d.cstride[0] + base;
+            T *o = out + (long long)dep * NIND * N + n;
+            if constexpr (NIND == 1) {
+                o[0] = contract1<T, O>(c, db[0]);
+            } else if constexpr (NIND == 2) {
+                const int s0 = d.cstride[1];
+                T j0 = T(0), j1 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T t = T(0), td = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        const T cv = c[a * s0 + k];
+                        t += cv * b[1][k];
+                        td += cv * db[1][k];
+                    }
+                    j0 += t * db[0][a];
+                    j1 += td * b[0][a];
+                }
+                o[0] = j0;
+                o[N] = j1;
+            } else {
+                const int s0 = d.cstride[1], s1 = d.cstride[2];
+                T j0 = T(0), j1 = T(0), j2 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T s = T(0), sb = T(0), sc = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        T t = T(0), td = T(0);
+#pragma unroll
+                        for (int m = 0; m < O; ++m) {
+                            const T cv = c[a * s0 + k * s1 + m];
+                            t += cv * b[2][m];
+                            td += cv * db[2][m];
+                        }
+                        s += t * b[1][k];
+                        sb += t * db[1][k];
+                        sc += td * b[1][k];
+                    }
+                    j0 += s * db[0][a];
+                    j1 += sb * b[0][a];
+                    j2 += sc * b[0][a];
+                }
+                o[0] = j0;
+                o[N] = j1;
+                o[2 * N] = j2;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// generic fallback: any nInd <= MAXI, any per-variable order <= MAXO.
+// Tables are read from global memory (L1/L2 resident), basis rows live in private memory.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void eval_generic(const Desc<T> d, const T *__restrict__ gtab,
+                                                    const T *__restrict__ gcoef, const Params<T> prm,
+                                                    const long long N, T *__restrict__ out,
+                                                    const long long ostride, const Wrt wrt,
+                                                    unsigned long long *bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T b[MAXI * MAXO];
+        int base = 0, win = 1;
+        bool outside = false;
+        for (int iv = 0; iv < d.nInd; ++iv) {
+            const T u = prm.p[iv][n];
+            outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
+            const T *tab = gtab + d.off[iv];
+            const int O = d.order[iv];
+            const int ix = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u);
+            basis_runtime<T>(tab, d.nk[iv], O, ix, u, wrt.w[iv], false, b + iv * MAXO);
+            base += (ix - O) * d.cstride[iv + 1];
+            win *= O;
+        }
+        if (outside) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            const T *__restrict__ c = gcoef + dep * d.cstride[0] + base;
+            // odometer over the window, last variable fastest; the weight of an element is
+            // the product of its per-variable basis values
+            int idx[MAXI];
+            for (int iv = 0; iv < d.nInd; ++iv) idx[iv] = 0;
+            T acc = T(0);
+            for (int w = 0; w < win; ++w) {
+                int off = 0;
+                T wgt = T(1);
+                for (int iv = 0; iv < d.nInd; ++iv) {
+                    off += idx[iv] * d.cstride[iv + 1];
+                    wgt *= b[iv * MAXO + idx[iv]];
+                }
+                acc += c[off] * wgt;
+                for (int iv = d.nInd - 1; iv >= 0; --iv) {
+                    if (++idx[iv] < d.order[iv]) break;
+                    idx[iv] = 0;
+                }
+            }
+            out[dep * ostride + n] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// batched bspline_values: span index + basis row per parameter (reference
+// bspy/_spline_evaluation.py:4-27).  Also stage 1 of the tensor-product grid path.
+//   tab: axis table of ONE variable (knots + reciprocal rows), global memory.
+//   bad_flag (grid path): set ix negative-encoded?  no: out-of-domain entries are
+//   reported through `outside` (one byte per parameter) when it is not NULL.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void basis_rows(const T *__restrict__ tab, int nk, int order, int ncoef,
+                                                  int steps, const T *__restrict__ u, long long n, int wrt,
+                                                  int taylor, const int *__restrict__ knot_in,
+                                                  int *__restrict__ ix_out, T *__restrict__ basis_out,
+                                                  T lo, T hi, unsigned char *__restrict__ outside)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T x = u[i];
+    T b[MAXO];
+    const int ix = knot_in ? knot_in[i] : find_span<T>(tab, order, ncoef, steps, x);
+    basis_runtime<T>(tab, nk, order, ix, x, wrt, taylor != 0, b);
+    ix_out[i] = ix;
+    for (int k = 0; k < order; ++k) basis_out[i * order + k] = b[k];
+    if (outside) outside[i] = (x < lo) | (x > hi);
+}
+
+// ---------------------------------------------------------------------------------
+// tensor-product grid, stage 2: one lane per output point, last grid variable fastest
+// (coalesced stores).  Basis rows come from stage 1 (tiny, cache resident): the per-point
+// work is the window contraction only.
+//   ixs / rows: concatenated per variable; goff[iv] = first parameter of variable iv.
+// out[dep * total + flat]
+// ---------------------------------------------------------------------------------
+struct GridDims {
+    long long n[MAXI];     // grid points per variable
+    long long goff[MAXI];  // offset of variable iv in ixs / outside; rows offset = goff * order (see roff)
+    long long roff[MAXI];  // offset of variable iv in rows
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void grid_generic(const Desc<T> d, const T *__restrict__ gcoef,
+                                                    const GridDims g, const int *__restrict__ ixs,
+                                                    const T *__restrict__ rows,
+                                                    const unsigned char *__restrict__ outside,
+                                                    const long long total, T *__restrict__ out,
+                                                    unsigned long long *bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total; n += stride) {
+        long long rem = n;
+        const T *brow[MAXI];
+        int base = 0, win = 1;
+        bool out_of_domain = false;
+        for (int iv = d.nInd - 1; iv >= 0; --iv) {
+            const long long gi = rem % g.n[iv];
+            rem /= g.n[iv];
+            const int O = d.order[iv];
+            brow[iv] = rows + g.roff[iv] + gi * O;
+            base += (ixs[g.goff[iv] + gi] - O) * d.cstride[iv + 1];
+            out_of_domain |= outside[g.goff[iv] + gi] != 0;
+            win *= O;
+        }
+        if (out_of_domain) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            const T *__restrict__ c = gcoef + dep * d.cstride[0] + base;
+            int idx[MAXI];
+            for (int iv = 0; iv < d.nInd; ++iv) idx[iv] = 0;
+            T acc = T(0);
+            for (int w = 0; w < win; ++w) {
+                int off = 0;
+                T wgt = T(1);
+                for (int iv = 0; iv < d.nInd; ++iv) {
+                    off += idx[iv] * d.cstride[iv + 1];
+                    wgt *= brow[iv][idx[iv]];
+                }
+                acc += c[off] * wgt;
+                for (int iv = d.nInd - 1; iv >= 0; --iv) {
+                    if (++idx[iv] < d.order[iv]) break;
+                    idx[iv] = 0;
+                }
+            }
+            out[dep * total + n] = acc;
+        }
+    }
+}
+
+// Surface fast path of the grid: order O x O, coefficient window in registers per
+// (i0 row); one lane per output point along the last variable.
+template <typename T, int O>
+__global__ __launch_bounds__(256) void grid_surface(const Desc<T> d, const T *__restrict__ gcoef,
+                                                    const GridDims g, const int *__restrict__ ixs,
+                                                    const T *__restrict__ rows,
+                                                    const unsigned char *__restrict__ outside,
+                                                    T *__restrict__ out, unsigned long long *bad)
+{
+    // blockIdx.y = grid row (variable 0), x covers variable 1
+    const long long n1 = g.n[1], total = g.n[0] * g.n[1];
+    const long long i0 = blockIdx.y;
+    const int ix0 = ixs[g.goff[0] + i0];
+    const bool bad0 = outside[g.goff[0] + i0] != 0;
+    T b0[O];
+#pragma unroll
+    for (int a = 0; a < O; ++a) b0[a] = rows[g.roff[0] + i0 * O + a];
+    const int s0 = d.cstride[1];
+    for (long long i1 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i1 < n1;
+         i1 += (long long)gridDim.x * blockDim.x) {
+        const int ix1 = ixs[g.goff[1] + i1];
+        T b1[O];
+#pragma unroll
+        for (int k = 0; k < O; ++k) b1[k] = rows[g.roff[1] + i1 * O + k];
+        const long long flat = i0 * n1 + i1;
+        if (bad0 | (outside[g.goff[1] + i1] != 0)) record_bad(bad, flat);
+        const int base = (ix0 - O) * s0 + (ix1 - O);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            const T *__restrict__ c = gcoef + dep * d.cstride[0] + base;
+            out[dep * total + flat] = contract2<T, O>(c, s0, b0, b1);
+        }
+    }
+}
+
+}  // namespace bsk

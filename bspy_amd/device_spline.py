@@ -1,0 +1,249 @@
+"""
+``DeviceSpline``: the device-resident tables of one spline (a ``bsk_spline`` handle)
+and the raw batched calls on it.  This is the thinnest Python layer over the C ABI;
+``bspy_amd.Spline`` (the drop-in for ``bspy.Spline``) is built on it.
+
+All arrays are SoA: parameters one array per independent variable, results
+``(nDep, N)`` / ``(nDep, nInd, N)``.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _native as nv
+
+_default_device = None
+
+
+def set_device(index):
+    """Default GPU for new device tables (one process per GPU: set it to LOCAL_RANK)."""
+    global _default_device
+    _default_device = int(index)
+
+
+def get_device():
+    global _default_device
+    if _default_device is None:
+        import os
+        _default_device = int(os.environ.get("BSPY_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = nv.device_count()
+        if n > 0:
+            _default_device %= n
+    return _default_device
+
+
+def _destroy(handle):
+    try:
+        nv.lib().bsk_spline_destroy(handle)
+    except Exception:  # noqa: BLE001 - interpreter shutdown
+        pass
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class DeviceSpline:
+    """Knots + coefficients of one spline on one GPU.
+
+    Parameters mirror the canonical in-memory form of the reference ``Spline``
+    (bspy/spline.py:46-76): ``knots`` a sequence of ``nInd`` 1-D arrays,
+    ``coefs`` of shape ``(nDep, *nCoef)``.  ``dtype`` is the arithmetic type of
+    every call on this object (float32 or float64).
+    """
+
+    def __init__(self, order, nCoef, knots, coefs, dtype=np.float64, device=None):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self.device = get_device() if device is None else int(device)
+        self.order = tuple(int(o) for o in order)
+        self.nCoef = tuple(int(c) for c in nCoef)
+        self.nInd = len(self.order)
+        coefs = np.asarray(coefs)
+        self.nDep = int(coefs.shape[0])
+        self._ctype = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
+        ks, cf = self._host_tables(knots, coefs)
+        handle = ctypes.c_void_p()
+        st = nv.lib().bsk_spline_create(nv.dtype_code(self.dtype), self.device, self.nInd, self.nDep,
+                                        nv.int_array(self.order), nv.int_array(self.nCoef),
+                                        nv.ptr_array([k.ctypes.data for k in ks]), cf.ctypes.data,
+                                        ctypes.byref(handle))
+        nv.check(st)
+        self._handle = handle
+        self._finalizer = weakref.finalize(self, _destroy, handle)
+
+    def _host_tables(self, knots, coefs):
+        if len(knots) != self.nInd:
+            raise ValueError("len(knots) != nInd")
+        ks = [np.ascontiguousarray(k, self.dtype) for k in knots]
+        for k, o, c in zip(ks, self.order, self.nCoef):
+            if k.shape != (o + c,):
+                raise ValueError("knots array has the wrong length")
+        cf = np.ascontiguousarray(coefs, self.dtype)
+        if cf.shape != (self.nDep, *self.nCoef):
+            raise ValueError("coefs must have shape (nDep, *nCoef)")
+        return ks, cf
+
+    def update(self, knots, coefs):
+        """Re-upload knots/coefficients of the same shapes (after in-place mutation)."""
+        ks, cf = self._host_tables(knots, np.asarray(coefs))
+        nv.check(nv.lib().bsk_spline_update(self._handle, nv.ptr_array([k.ctypes.data for k in ks]), cf.ctypes.data))
+
+    def close(self):
+        self._finalizer()
+
+    # ------------------------------------------------------------------ host (NumPy) calls
+    def _host_params(self, points):
+        if len(points) != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {len(points)}")
+        ps = [np.ascontiguousarray(p, self.dtype).ravel() for p in points]
+        n = ps[0].size if ps else 0
+        if any(p.size != n for p in ps):
+            raise ValueError("parameter arrays must have the same size")
+        return ps, n
+
+    def evaluate(self, points, wrt=None):
+        """points: nInd arrays of N values -> ndarray (nDep, N).  Raises DomainError."""
+        ps, n = self._host_params(points)
+        out = np.empty((self.nDep, n), self.dtype)
+        bad = ctypes.c_int64(-1)
+        st = nv.lib().bsk_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None,
+                                   nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST, out.ctypes.data, None,
+                                   ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
+    def jacobian(self, points):
+        """points: nInd arrays of N values -> ndarray (nDep, nInd, N)."""
+        ps, n = self._host_params(points)
+        out = np.empty((self.nDep, self.nInd, n), self.dtype)
+        bad = ctypes.c_int64(-1)
+        st = nv.lib().bsk_jacobian(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
+                                   out.ctypes.data, None, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
+    def evaluate_grid(self, axes, wrt=None):
+        """axes: nInd 1-D arrays (n_i values) -> ndarray (nDep, n_0, ..., n_{nInd-1})."""
+        if len(axes) != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {len(axes)}")
+        gs = [np.ascontiguousarray(a, self.dtype).ravel() for a in axes]
+        shape = tuple(g.size for g in gs)
+        out = np.empty((self.nDep, *shape), self.dtype)
+        bad = ctypes.c_int64(-1)
+        ng = (ctypes.c_int64 * max(self.nInd, 1))(*shape)
+        st = nv.lib().bsk_evaluate_grid(self._handle, nv.int_array(wrt) if wrt is not None else None,
+                                        nv.ptr_array([g.ctypes.data for g in gs]), ng, nv.BSK_HOST, out.ctypes.data,
+                                        None, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
+    # ------------------------------------------------------------------ device (torch) calls
+    def _torch_params(self, points):
+        import torch
+        if len(points) != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {len(points)}")
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        ps = []
+        for p in points:
+            if not (_is_torch(p) and p.is_cuda):
+                raise TypeError("device calls need CUDA/HIP torch tensors for every variable")
+            if p.device.index != self.device:
+                raise ValueError(f"tensor on device {p.device.index}, spline tables on device {self.device}")
+            ps.append(p.to(tdt).contiguous().view(-1))
+        n = ps[0].numel() if ps else 0
+        if any(p.numel() != n for p in ps):
+            raise ValueError("parameter tensors must have the same number of elements")
+        return torch, tdt, ps, n
+
+    @staticmethod
+    def _stream_ptr(torch, device):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def evaluate_device(self, points, wrt=None, out=None, check=True):
+        """points: nInd CUDA tensors -> CUDA tensor (nDep, N), enqueued on torch's current
+        stream.  ``check=False`` skips the (synchronising) out-of-domain query; call
+        ``domain_status()`` later."""
+        torch, tdt, ps, n = self._torch_params(points)
+        if out is None:
+            out = torch.empty((self.nDep, n), dtype=tdt, device=ps[0].device)
+        elif out.dtype != tdt or out.numel() != self.nDep * n or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (nDep, N) tensor of the spline's dtype")
+        st = nv.lib().bsk_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None,
+                                   nv.ptr_array([p.data_ptr() for p in ps]), n, nv.BSK_DEVICE, out.data_ptr(),
+                                   self._stream_ptr(torch, self.device), None)
+        nv.check(st)
+        if check:
+            self.domain_status()
+        return out
+
+    def jacobian_device(self, points, out=None, check=True):
+        """points: nInd CUDA tensors -> CUDA tensor (nDep, nInd, N)."""
+        torch, tdt, ps, n = self._torch_params(points)
+        if out is None:
+            out = torch.empty((self.nDep, self.nInd, n), dtype=tdt, device=ps[0].device)
+        elif out.dtype != tdt or out.numel() != self.nDep * self.nInd * n or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (nDep, nInd, N) tensor of the spline's dtype")
+        st = nv.lib().bsk_jacobian(self._handle, nv.ptr_array([p.data_ptr() for p in ps]), n, nv.BSK_DEVICE,
+                                   out.data_ptr(), self._stream_ptr(torch, self.device), None)
+        nv.check(st)
+        if check:
+            self.domain_status()
+        return out
+
+    def evaluate_grid_device(self, axes, wrt=None, out=None, check=True):
+        """axes: nInd 1-D CUDA tensors -> CUDA tensor (nDep, n_0, ..., n_{nInd-1})."""
+        import torch
+        if len(axes) != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {len(axes)}")
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        gs = [a.to(tdt).contiguous().view(-1) for a in axes]
+        shape = tuple(int(g.numel()) for g in gs)
+        if out is None:
+            out = torch.empty((self.nDep, *shape), dtype=tdt, device=gs[0].device)
+        ng = (ctypes.c_int64 * max(self.nInd, 1))(*shape)
+        st = nv.lib().bsk_evaluate_grid(self._handle, nv.int_array(wrt) if wrt is not None else None,
+                                        nv.ptr_array([g.data_ptr() for g in gs]), ng, nv.BSK_DEVICE, out.data_ptr(),
+                                        self._stream_ptr(torch, self.device), None)
+        nv.check(st)
+        if check:
+            self.domain_status()
+        return out
+
+    def domain_status(self):
+        """Synchronise and raise DomainError if any device call since the last query met an
+        out-of-domain parameter."""
+        stream = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                stream = self._stream_ptr(torch, self.device)
+        except ImportError:  # pragma: no cover
+            pass
+        bad = ctypes.c_int64(-1)
+        st = nv.lib().bsk_domain_status(self._handle, stream, ctypes.byref(bad))
+        nv.check(st, bad)
+
+
+def bspline_values_batch(knots, order, u, derivative_order=0, taylor_coefs=False, knot=None, device=None):
+    """Batched basis values: returns (ix int32 (N,), basis (N, order)) in the knots' dtype
+    (float32 stays float32, everything else is computed in float64)."""
+    knots = np.asarray(knots)
+    dt = np.float32 if knots.dtype == np.float32 else np.float64
+    knots = np.ascontiguousarray(knots, dt)
+    u = np.ascontiguousarray(u, dt).ravel()
+    n = u.size
+    ix = np.empty(n, np.int32)
+    basis = np.empty((n, int(order)), dt)
+    kin = None
+    if knot is not None:
+        kin_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(knot, np.int32), (n,)))
+        kin = kin_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    st = nv.lib().bsk_bspline_values(nv.dtype_code(dt), get_device() if device is None else int(device),
+                                     knots.ctypes.data, knots.size, int(order), u.ctypes.data, n,
+                                     int(derivative_order), 1 if taylor_coefs else 0, kin,
+                                     ix.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), basis.ctypes.data)
+    nv.check(st)
+    return ix, basis

@@ -1,0 +1,138 @@
+/*
+ * bspy_amd.h - C ABI of libbspy_amd.so: MI355X (gfx950) batched B-spline evaluation.
+ *
+ * The reference (ericbrec/BSpy 5.0.1) is pure Python and has no FFI of its own; its
+ * boundary for this path is the Python API.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference
+ * checkout).  The reference-side binding a maintainer would add is the ctypes stub
+ * shown in INTEGRATION.md; bspy_amd/_native.py is that stub in full.
+ *
+ * Conventions
+ *  - plain C types only; no exceptions, no Python objects, no torch types.
+ *  - every function returns a bsk_status (0 = ok).  bsk_last_error() returns a
+ *    thread-local, human readable message for the last non-zero status.
+ *  - dtype: BSK_F32 or BSK_F64.  It is the arithmetic type of the whole call:
+ *    knots, coefficients, parameters and results all have it (the Python layer
+ *    promotes mixed inputs, see bspy_amd/spline.py).
+ *  - parameter points are SoA: one pointer per independent variable, each to n
+ *    contiguous values.  Results are SoA: out[d * n + i] (evaluate/derivative),
+ *    out[(d * nInd + j) * n + i] (jacobian).
+ *  - mem: BSK_HOST buffers are copied to/from the device by the library (PCIe in the
+ *    call); BSK_DEVICE buffers are device pointers on the spline's device and the call
+ *    only enqueues work on `stream` (a hipStream_t, NULL = default stream).
+ *  - the caller owns every buffer it passes; the library owns the device tables
+ *    behind a bsk_spline handle.  Handles are not thread safe; distinct handles are
+ *    independent.
+ */
+#ifndef BSPY_AMD_H
+#define BSPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSK_VERSION 1
+
+#define BSK_MAX_NIND 8     /* independent variables per spline */
+#define BSK_MAX_ORDER 16   /* polynomial order (degree + 1) per variable */
+
+typedef enum { BSK_F32 = 0, BSK_F64 = 1 } bsk_dtype;
+typedef enum { BSK_HOST = 0, BSK_DEVICE = 1 } bsk_mem;
+
+typedef enum {
+    BSK_OK = 0,
+    BSK_ERR_INVALID = 1,      /* bad argument (message says which) */
+    BSK_ERR_DOMAIN = 2,       /* a parameter lies outside the spline's domain; *first_bad = its flat index */
+    BSK_ERR_HIP = 3,          /* HIP runtime failure */
+    BSK_ERR_NO_DEVICE = 4,    /* no usable gfx950 device */
+    BSK_ERR_UNSUPPORTED = 5   /* nInd / order beyond BSK_MAX_* */
+} bsk_status;
+
+typedef struct bsk_spline_s *bsk_spline;
+
+/* Library / device information. */
+int bsk_version(void);
+const char *bsk_last_error(void);
+bsk_status bsk_device_count(int *count);
+
+/*
+ * Spline handle = the device-resident tables of one reference `Spline` object.
+ * Replaces: Spline.__init__ storage, bspy/spline.py:46-76 (validation stays in Python).
+ *   knots[iv]  : order[iv] + nCoef[iv] values, non-decreasing
+ *   coefs      : C-contiguous (nDep, nCoef[0], ..., nCoef[nInd-1])
+ * The data is copied; bsk_spline_update re-uploads after the Python object's
+ * knots/coefs were mutated (same shapes).
+ */
+bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, int nDep,
+                             const int *order, const int *nCoef,
+                             const void *const *knots, const void *coefs,
+                             bsk_spline *out);
+bsk_status bsk_spline_update(bsk_spline s, const void *const *knots, const void *coefs);
+bsk_status bsk_spline_destroy(bsk_spline s);
+
+/*
+ * Batched evaluate / derivative.
+ * Replaces: Spline.evaluate / Spline.derivative batched through np.frompyfunc,
+ *   bspy/spline.py:936-949 and :757-770, i.e. one call of
+ *   bspy/_spline_evaluation.py:140-164 (evaluate) / :109-133 (derivative) per point,
+ *   including its span search and de Boor recursion (:4-27).
+ *   wrt        : nInd derivative orders, or NULL for plain evaluation
+ *   uvw[iv]    : n parameter values of variable iv
+ *   out        : nDep * n results, out[d * n + i]
+ *   first_bad  : (may be NULL) receives -1, or the index of the first point outside
+ *                the inclusive domain [knots[order-1], knots[nCoef]] (status
+ *                BSK_ERR_DOMAIN; the reference raises ValueError for that point,
+ *                _spline_evaluation.py:148-152).  NaN parameters pass, as there.
+ * With mem == BSK_DEVICE the call is asynchronous and never reports BSK_ERR_DOMAIN
+ * itself: use bsk_domain_status() after the work was enqueued.
+ */
+bsk_status bsk_evaluate(bsk_spline s, const int *wrt, const void *const *uvw, int64_t n,
+                        bsk_mem mem, void *out, void *stream, int64_t *first_bad);
+
+/*
+ * Batched jacobian: all first partial derivatives in one pass.
+ * Replaces: Spline.jacobian / tangent_space, bspy/_spline_evaluation.py:205-213
+ *   (nInd calls of derivative per point; single point only in the reference).
+ *   out        : nDep * nInd * n results, out[(d * nInd + j) * n + i]
+ */
+bsk_status bsk_jacobian(bsk_spline s, const void *const *uvw, int64_t n,
+                        bsk_mem mem, void *out, void *stream, int64_t *first_bad);
+
+/*
+ * Tensor-product grid evaluation: parameters are the outer product of per-variable
+ * vectors (the reference's broadcast call s(u[:, None], v[None, :]), bspy/spline.py:941-945).
+ *   grid[iv]   : ngrid[iv] values of variable iv
+ *   out        : nDep * prod(ngrid) results, C order (d, i0, i1, ...)
+ *   first_bad  : flat index into the broadcast shape (i0, i1, ...) of the first offender
+ */
+bsk_status bsk_evaluate_grid(bsk_spline s, const int *wrt, const void *const *grid, const int64_t *ngrid,
+                             bsk_mem mem, void *out, void *stream, int64_t *first_bad);
+
+/*
+ * Synchronise `stream` and report whether any BSK_DEVICE call on this handle since the
+ * last bsk_domain_status() met an out-of-domain parameter (*first_bad = smallest such
+ * index, else -1).  Resets the record.
+ */
+bsk_status bsk_domain_status(bsk_spline s, void *stream, int64_t *first_bad);
+
+/*
+ * Batched B-spline basis values (no spline object).
+ * Replaces: Spline.bspline_values, bspy/spline.py:207-252 -> bspy/_spline_evaluation.py:4-27.
+ *   knot_in    : NULL to search the span of every u (reference: knot=None), else n
+ *                explicit span indices
+ *   ix_out     : n span indices ("rightmost knot of the segment")
+ *   basis_out  : n * order values, basis_out[i * order + k] multiplies coefficient
+ *                ix_out[i] - order + k
+ * Host buffers only (this is the low-rate public helper; the evaluation kernels have
+ * the same recursion fused in).
+ */
+bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void *knots, int nknots, int order,
+                              const void *u, int64_t n, int derivative_order, int taylor_coefs,
+                              const int32_t *knot_in, int32_t *ix_out, void *basis_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSPY_AMD_H */

@@ -1,0 +1,322 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(bspy_amd.DeviceSpline -> ctypes -> libbspy_amd.so), against
+  * outputs of the reference itself (tests/golden/parity.npz, basis.npz, reference_tables.npz),
+  * the CPU oracle (oracle/) on the same seeded inputs,
+  * size-independent properties at the BASELINE size (10 M points).
+Tolerances: fp64 1e-10 (BASELINE.json north_star), asserted far tighter (1e-12 of the
+result scale) where the arithmetic allows; fp32 cases 2e-5 of the result scale.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import bspy_amd
+from bspy_amd import DeviceSpline, Spline
+
+pytestmark = pytest.mark.gpu
+
+CASES = {c.name: c for c in cases.parity_cases()}
+EPS = np.finfo(float).eps
+
+
+def _is_f32(c):
+    return c.knots[0].dtype == np.float32 and c.coefs.dtype == np.float32
+
+
+def _tol(c):
+    if _is_f32(c):
+        return 2e-5
+    if c.knots[0].dtype == np.float32 or c.coefs.dtype == np.float32:
+        return 2e-5          # the reference rounds its basis / result to fp32 in these cases
+    return 1e-12
+
+
+def _scale(ref):
+    return max(1.0, float(np.max(np.abs(ref))))
+
+
+def _tables(c):
+    dt = np.float32 if _is_f32(c) else np.float64
+    return DeviceSpline(c.order, c.nCoef, c.knots, c.coefs, dt)
+
+
+def test_library_is_native():
+    assert bspy_amd._native.lib().bsk_version() == 1
+    assert bspy_amd._native.device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_evaluate_derivative_against_reference(name, golden_parity):
+    c = CASES[name]
+    t = _tables(c)
+    tol = _tol(c)
+    for w in c.wrts:
+        ref = golden_parity[f"{name}/wrt_" + "_".join(map(str, w))]
+        out = t.evaluate(c.points, list(w))
+        assert out.shape == ref.shape
+        err = np.abs(out - ref).max()
+        assert err <= tol * _scale(ref), (name, w, err)
+        orc, bad = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, list(w), c.points)
+        assert bad == -1
+        assert np.abs(out - orc).max() <= tol * _scale(orc), (name, w)
+    # plain evaluation with wrt == None is the same kernel path as all-zero wrt
+    zero = tuple([0] * c.nInd)
+    if zero in c.wrts:
+        assert np.array_equal(t.evaluate(c.points), t.evaluate(c.points, list(zero)))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_jacobian_against_reference(name, golden_parity):
+    c = CASES[name]
+    t = _tables(c)
+    ref = golden_parity[f"{name}/jac"].transpose(1, 2, 0)      # (nDep, nInd, N)
+    out = t.jacobian(c.points)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= _tol(c) * _scale(ref)
+    orc, bad = oracle.c_jacobian(c.order, c.nCoef, c.knots, c.coefs, c.points)
+    assert np.abs(out - orc).max() <= _tol(c) * _scale(orc)
+
+
+def test_reference_truth_tables(golden_tables):
+    """The reference's own test_evaluate / test_derivative tables through the Spline API."""
+    t = golden_tables
+    curve = Spline(1, 2, [4], [5], [t["curve_knots0"]], t["curve_coefs"])
+    tc = t["truthCurve"]
+    x, y = curve(tc[:, 0])
+    assert np.sqrt((x - tc[:, 1]) ** 2 + (y - tc[:, 2]) ** 2).max() <= 8 * EPS
+    for u, xr, yr in tc[::20]:
+        xt, yt = curve.evaluate([u])
+        assert np.hypot(xt - xr, yt - yr) <= 8 * EPS
+    surf = Spline(2, 3, [3, 4], [4, 5], [t["surface_knots0"], t["surface_knots1"]], t["surface_coefs"])
+    g = np.linspace(0, 1, 21)
+    v, u = np.meshgrid(g, g, indexing="ij")
+    xyz = np.stack(surf(u.ravel(), v.ravel())).T
+    d = xyz - t["truthSurface"]
+    assert np.sqrt((d * d).sum(axis=1)).max() <= 16 * EPS
+    dx, dy = curve.derivative([1], tc[:, 0])
+    dd = np.stack([dx, dy]).T - t["curve_differentiate_eval"]
+    assert (dd * dd).sum(axis=1).max() <= 1e-26
+    assert np.abs(surf.jacobian([0.25, 0.5]) - t["surface_jacobian_025_05"]).max() <= 64 * EPS
+
+
+def test_bspline_values_goldens(golden_basis):
+    ix_ref, basis_ref = golden_basis["ix"], golden_basis["basis"]
+    bc = cases.basis_cases()
+    # group by (knots identity, order, deriv, taylor, explicit) so each group is one batched call
+    groups = {}
+    for k, (knots, order, u, deriv, taylor, knot) in enumerate(bc):
+        groups.setdefault((id(knots), order, deriv, taylor, knot is not None), []).append(k)
+    for (_, order, deriv, taylor, explicit), idxs in groups.items():
+        knots = bc[idxs[0]][0]
+        us = np.array([bc[k][2] for k in idxs], knots.dtype)
+        kin = np.array([bc[k][5] for k in idxs], np.int32) if explicit else None
+        ix, basis = bspy_amd.bspline_values_batch(knots, order, us, deriv, taylor, kin)
+        assert np.array_equal(ix, ix_ref[idxs])
+        ref = basis_ref[idxs, :order]
+        tol = (4e-6 if knots.dtype == np.float32 else 1e-12) * max(1.0, np.abs(ref).max())
+        assert np.abs(basis - ref).max() <= tol
+    # scalar form of the static method
+    knots, order, u, deriv, taylor, knot = bc[5]
+    ix, b = Spline.bspline_values(knot, knots, order, u, deriv, taylor)
+    assert isinstance(ix, int) and ix == ix_ref[5] and b.shape == (order,) and b.dtype == knots.dtype
+
+
+def test_api_semantics(golden_api):
+    a = golden_api
+    k = [0, 0, 0, 0, .3, .3, .7, 1, 1, 1, 1]
+    s = Spline(1, 2, [4], [7], [k], np.arange(14.0).reshape(2, 7))
+    assert [int(Spline.bspline_values(None, np.array(k), 4, u)[0]) for u in (0.0, 0.3, 0.7, 1.0)] == a["span_at_knots"]
+
+    def err(f):
+        try:
+            f()
+        except Exception as e:  # noqa: BLE001
+            return [type(e).__name__, str(e)]
+        return None
+
+    assert err(lambda: s.evaluate([1.5])) == a["err_outside_scalar"]
+    assert err(lambda: s(np.array([0.1, 0.2, -0.25, 3.0]))) == a["err_outside_batch"]
+    assert err(lambda: s.evaluate([0.1, 0.2])) == a["err_arity"]
+    assert err(lambda: s.derivative([1], [-0.5])) == a["err_outside_deriv"]
+    s2 = Spline(2, 3, [3, 4], [4, 5], [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]],
+                np.arange(60.0).reshape(3, 4, 5))
+    assert err(lambda: s2(np.array([0.1, 0.2, 0.3]), np.array([0.5, 1.25, 7.0]))) == a["err_outside_batch2"]
+    assert err(lambda: s2.evaluate([0.1])) == a["err_arity2"]
+
+    def chk(r, rec):
+        assert list(r.shape) == rec[0] and str(r.dtype) == rec[1]
+        assert np.allclose(r, rec[2], rtol=0, atol=1e-13)
+
+    chk(s.evaluate([0.25]), a["scalar_list_shape"])
+    chk(s.evaluate(0.25), a["scalar_shape"])
+    chk(s2(0.25, 0.5), a["scalar2_shape"])
+    chk(s2([0.25, 0.5]), a["scalar2_list_shape"])
+    chk(s2(np.array([0.25, 0.5])), a["scalar2_ndarray_shape"])
+    r = s(np.array([0.25, 0.5, 0.75]))
+    assert [type(r).__name__, len(r), list(r[0].shape), str(r[0].dtype)] == a["batch_type"]
+    s1 = Spline(1, 1, [4], [7], [k], np.arange(7.0))
+    r = s1(np.array([0.25, 0.5, 0.75]))
+    assert [type(r).__name__, list(r.shape), str(r.dtype)] == a["batch_ndep1_type"][:3]
+    assert np.allclose(r, a["batch_ndep1_type"][3], rtol=0, atol=1e-13)
+    u = np.linspace(0, 1, 5)
+    r = s2(u[:, None], u[None, :])
+    assert [type(r).__name__, len(r), list(r[0].shape)] == a["grid_type"]
+    assert np.allclose(np.stack(r), np.array(a["grid_values"]), rtol=0, atol=1e-12)
+    assert np.allclose(np.stack(s2(u, 0.5)), np.array(a["array_scalar_values"]), rtol=0, atol=1e-12)
+    assert np.allclose(np.stack(s2.derivative([1, 0], u, 0.5)), np.array(a["array_scalar_deriv_values"]), rtol=0, atol=1e-12)
+    assert np.allclose(s2.jacobian([0.25, 0.5]), np.array(a["jacobian"]), rtol=0, atol=1e-12)
+    assert np.allclose(s2.tangent_space([0.25, 0.5]), np.array(a["tangent_space"]), rtol=0, atol=1e-12)
+    assert np.isnan(s.evaluate([float("nan")])).all()
+    assert s.derivative([4], [0.5]).tolist() == a["zero_derivative"]
+
+
+def test_grid_broadcast_matches_flat():
+    c = CASES["surface_o3x4"]
+    s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    dom = s.domain()
+    u = np.linspace(dom[0][0], dom[0][1], 97)
+    v = np.linspace(dom[1][0], dom[1][1], 131)
+    for w in ([0, 0], [1, 0], [1, 2]):
+        g = np.stack(s.derivative(w, u[:, None], v[None, :]))                     # grid path (> 4096 points)
+        uu, vv = np.meshgrid(u, v, indexing="ij")
+        f = np.stack(s.derivative(w, uu.ravel(), vv.ravel())).reshape(g.shape)     # flat path
+        assert np.abs(g - f).max() <= 1e-12 * _scale(f)
+    # transposed broadcast: variable 0 along the last axis
+    g = np.stack(s(u[None, :], v[:, None]))
+    uu, vv = np.meshgrid(u, v, indexing="xy")
+    f = np.stack(s(uu.ravel(), vv.ravel())).reshape(g.shape)
+    assert g.shape == (3, 131, 97) and np.abs(g - f).max() <= 1e-12 * _scale(f)
+    # same-order surface uses the surface grid kernel; three variables the generic one
+    for name in ("cfg2_bicubic", "volume_o3x4x2"):
+        c = CASES[name]
+        s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+        dom = s.domain()
+        axes = [np.linspace(dom[i][0], dom[i][1], 19 + 4 * i) for i in range(c.nInd)]
+        t = s.device_tables()
+        g = t.evaluate_grid(axes)
+        mesh = np.meshgrid(*axes, indexing="ij")
+        f = t.evaluate([m.ravel() for m in mesh]).reshape(g.shape)
+        assert np.abs(g - f).max() <= 1e-12 * _scale(f)
+    # out-of-domain value on a grid: first offender in broadcast order
+    u2 = u.copy()
+    u2[5] = 99.0
+    c = CASES["surface_o3x4"]
+    s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    with pytest.raises(ValueError, match="Spline evaluation outside domain"):
+        s(u2[:, None], v[None, :])
+
+
+def test_teapot_grid(golden_tables):
+    """cfg4 shape: the 32 Utah-teapot patches (examples/teapot.py:4-358) on a broadcast grid, fp32."""
+    t = golden_tables
+    knots = np.array((0, 0, 0, 0, 1, 1, 1, 1), np.float32)
+    g = np.linspace(0, 1, 16, dtype=np.float32)
+    g2 = np.linspace(0, 1, 96, dtype=np.float32)
+    V = t["teapot_vertices"]
+    for pi, patch in enumerate(t["teapot_patch_index"]):
+        c = np.empty((3, 4, 4), np.float32)
+        for i in range(4):
+            for j in range(4):
+                v = V[patch[4 * i + j] - 1]
+                c[0, i, j], c[1, i, j], c[2, i, j] = v[0], v[2], v[1]
+        s = Spline(2, 3, (4, 4), (4, 4), (knots, knots), c)
+        out = np.stack(s(g[:, None], g[None, :]))
+        assert out.dtype == np.float32
+        assert np.abs(out - t["teapot_grid16"][pi]).max() <= 2e-5 * _scale(t["teapot_grid16"][pi])
+        # grid kernel (96 x 96 > threshold) agrees with the flat kernel on the same points
+        big = np.stack(s(g2[:, None], g2[None, :]))
+        uu, vv = np.meshgrid(g2, g2, indexing="ij")
+        flat = np.stack(s(uu.ravel(), vv.ravel())).reshape(big.shape)
+        assert np.abs(big - flat).max() <= 2e-5 * _scale(flat)
+
+
+def test_constructor_forms_and_mutation(golden_api):
+    k2 = [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]]
+    flat = np.arange(60.0).reshape(20, 3)
+    s3 = Spline(2, 3, [3, 4], [4, 5], k2, flat)                      # flat list-of-points form
+    assert np.array_equal(np.ascontiguousarray(s3.coefs), np.array(golden_api["flat_coefs"]))
+    ref = Spline(2, 3, [3, 4], [4, 5], k2, np.ascontiguousarray(s3.coefs))
+    assert np.array_equal(s3([0.3, 0.6]), ref([0.3, 0.6]))           # non-contiguous coefs view is handled
+    # in-place mutation of coefs must invalidate the device tables
+    before = ref([0.3, 0.6]).copy()
+    ref.coefs[:, 1, 2] += 10.0
+    after = ref([0.3, 0.6])
+    assert np.abs(after - before).max() > 1e-3
+    fresh = Spline(2, 3, [3, 4], [4, 5], k2, ref.coefs.copy())
+    assert np.array_equal(after, fresh([0.3, 0.6]))
+    # integer inputs are promoted to float64 (documented deviation)
+    si = Spline(1, 1, [4], [4], [[0, 0, 0, 0, 1, 1, 1, 1]], [[0, 1, 2, 3]])
+    assert abs(si(0.5)[0] - 1.5) < 1e-14
+
+
+def test_torch_device_path_matches_host_path():
+    torch = pytest.importorskip("torch")
+    c = CASES["cfg2_bicubic"]
+    s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    host = np.stack(s(*c.points))
+    dev = s(*[torch.as_tensor(p, device="cuda") for p in c.points])
+    assert isinstance(dev, tuple) and dev[0].is_cuda
+    assert np.array_equal(torch.stack(dev).cpu().numpy(), host)      # same kernel, bitwise
+    jh = s.jacobian(c.points)
+    jd = s.jacobian([torch.as_tensor(p, device="cuda") for p in c.points])
+    assert np.array_equal(jd.cpu().numpy(), jh)
+    bad = [torch.as_tensor(p.copy(), device="cuda") for p in c.points]
+    bad[1][17] = 5.0
+    with pytest.raises(ValueError, match="Spline evaluation outside domain"):
+        s(*bad)
+    s(*[torch.as_tensor(p, device="cuda") for p in c.points])         # the record was reset
+
+
+def test_full_size_properties():
+    """BASELINE cfg2 size: 10 M random points on the bicubic 64x64x3 fp64 surface."""
+    nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(2)
+    n = 10_000_000
+    rng = np.random.default_rng(0)
+    uv = rng.random((2, n))
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    out = t.evaluate([uv[0], uv[1]])
+    # (a) oracle on a 200 k sample spread over the batch
+    idx = rng.choice(n, 200_000, replace=False)
+    orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [uv[0][idx], uv[1][idx]])
+    assert bad == -1
+    assert np.abs(out[:, idx] - orc).max() <= 1e-12 * _scale(orc)
+    # (b) determinism: bitwise identical on a second run
+    assert np.array_equal(out, t.evaluate([uv[0], uv[1]]))
+    # (c) permutation equivariance, bitwise (no dependence on a point's position in the batch)
+    perm = rng.permutation(n)
+    assert np.array_equal(out[:, perm], t.evaluate([uv[0][perm], uv[1][perm]]))
+    # (d) partition of unity: all coefficients 1 -> value 1, first derivatives 0
+    ones = DeviceSpline(order, ncoef, knots, np.ones_like(coefs), dt)
+    assert np.abs(ones.evaluate([uv[0], uv[1]]) - 1.0).max() <= 64 * EPS
+    jac = ones.jacobian([uv[0][:1_000_000], uv[1][:1_000_000]])
+    assert np.abs(jac).max() <= 1e-10
+    # (e) linearity in the coefficients
+    c2 = np.random.default_rng(1).standard_normal(coefs.shape)
+    both = DeviceSpline(order, ncoef, knots, coefs + 2.0 * c2, dt).evaluate([uv[0], uv[1]])
+    second = DeviceSpline(order, ncoef, knots, c2, dt).evaluate([uv[0], uv[1]])
+    assert np.abs(both - (out + 2.0 * second)).max() <= 1e-12 * _scale(both)
+    # (f) jacobian agrees with the two derivative calls at full size (cfg3)
+    m = 2_000_000
+    jac = t.jacobian([uv[0][:m], uv[1][:m]])
+    d0 = t.evaluate([uv[0][:m], uv[1][:m]], [1, 0])
+    d1 = t.evaluate([uv[0][:m], uv[1][:m]], [0, 1])
+    assert np.abs(jac[:, 0] - d0).max() <= 1e-11 * _scale(d0)
+    assert np.abs(jac[:, 1] - d1).max() <= 1e-11 * _scale(d1)
+
+
+def test_empty_and_ragged():
+    c = CASES["cfg2_bicubic"]
+    t = _tables(c)
+    assert t.evaluate([np.empty(0), np.empty(0)]).shape == (3, 0)
+    assert t.jacobian([np.empty(0), np.empty(0)]).shape == (3, 2, 0)
+    with pytest.raises(ValueError):
+        t.evaluate([c.points[0], c.points[1][:-1]])
+    with pytest.raises(ValueError, match="Incorrect number of parameter values: 1"):
+        t.evaluate([c.points[0]])
+    # every batch size around the workgroup/wave boundaries
+    for n in (1, 63, 64, 65, 255, 256, 257, 1023, 1024):
+        out = t.evaluate([c.points[0][:n], c.points[1][:n]])
+        orc, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, [0, 0], [c.points[0][:n], c.points[1][:n]])
+        assert np.abs(out - orc).max() <= 1e-12 * _scale(orc)
