@@ -66,6 +66,14 @@ def lib():
         raise NativeLibraryError(
             f"{LIB_PATH} not found. Build it with `make -C {os.path.dirname(LIB_PATH)}` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). bspy_amd has no CPU fallback.")
+    if not os.environ.get("BSPY_AMD_NO_TORCH"):
+        # PyTorch-ROCm ships its own libamdhip64; if it is going to be used in this process it
+        # must be the first HIP runtime loaded (a second copy finds "no HIP GPUs"), so let it
+        # load before libbspy_amd.so resolves the same SONAME.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the machine
