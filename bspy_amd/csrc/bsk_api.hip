@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "bsk_kernels.hpp"
+#include "bsk_tile.hpp"
 
 using namespace bsk;
 
@@ -62,8 +63,12 @@ struct bsk_spline_s {
     size_t esize;
     Desc<float> d32;
     Desc<double> d64;
+    TileDesc<float> t32;
+    TileDesc<double> t64;
     void *tab = nullptr;     // device axis table
     void *coef = nullptr;    // device coefficients
+    unsigned *lut = nullptr; // device span-search bucket tables
+    int variant = 0;         // BSK_VARIANT override: 0 auto, 1 simple, 2 tile, 3 tile + bank permutation
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -76,6 +81,12 @@ template <>
 Desc<float> &desc_of<float>(bsk_spline s) { return s->d32; }
 template <>
 Desc<double> &desc_of<double>(bsk_spline s) { return s->d64; }
+template <typename T>
+static TileDesc<T> &tile_of(bsk_spline s);
+template <>
+TileDesc<float> &tile_of<float>(bsk_spline s) { return s->t32; }
+template <>
+TileDesc<double> &tile_of<double>(bsk_spline s) { return s->t64; }
 
 static int ceil_log2(int x)
 {
@@ -98,21 +109,67 @@ static void build_axis_table(const T *knots, int order, int nk, std::vector<T> &
         }
 }
 
+// searchsorted(knots, x, 'right') clamped to [order, ncoef]: the reference's span rule
+// (bspy/_spline_evaluation.py:6-8) on the host, for the bucket tables.
+template <typename T>
+static int host_span(const T *knots, int order, int ncoef, double x)
+{
+    int lo = order, hi = ncoef;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if ((double)knots[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+static int lut_buckets(int order, int ncoef)
+{
+    int m = 16;
+    while (m < 4 * (ncoef - order + 1) && m < 4096) m <<= 1;
+    return m;
+}
+
+// Bucket table of one variable: bucket b covers parameters with int((u - lo) * scale) == b;
+// entry = lo_ix | hi_ix << 16 brackets the span of every such u.  The bracket is widened by
+// 1 % of a bucket on both sides, far more than the rounding of the device's (u - lo) * scale.
+template <typename T>
+static void build_lut(const T *knots, int order, int ncoef, int m, T &scale, int &steps, std::vector<unsigned> &lut)
+{
+    const double lo = (double)knots[order - 1], hi = (double)knots[ncoef];
+    const double w = hi - lo;
+    scale = T((double)m / w);
+    const double inv = 1.0 / (double)scale;
+    int widest = 0;
+    for (int b = 0; b < m; ++b) {
+        const int l = host_span<T>(knots, order, ncoef, lo + ((double)b - 0.01) * inv);
+        const int h = (b == m - 1) ? ncoef : host_span<T>(knots, order, ncoef, lo + ((double)b + 1.01) * inv);
+        widest = std::max(widest, h - l);
+        lut.push_back((unsigned)l | ((unsigned)h << 16));
+    }
+    steps = ceil_log2(widest + 1);
+}
+
 template <typename T>
 static bsk_status upload_tables(bsk_spline s, const void *const *knots, const void *coefs)
 {
     Desc<T> &d = desc_of<T>(s);
+    TileDesc<T> &td = tile_of<T>(s);
     std::vector<T> tab;
+    std::vector<unsigned> lut;
     for (int iv = 0; iv < s->nInd; ++iv) {
         d.off[iv] = (int)tab.size();
         const T *k = static_cast<const T *>(knots[iv]);
         build_axis_table<T>(k, s->order[iv], d.nk[iv], tab);
         d.lo[iv] = k[s->order[iv] - 1];          // domain: reference _spline_evaluation.py:135-138
         d.hi[iv] = k[s->ncoef[iv]];
+        td.lut_off[iv] = (int)lut.size();
+        build_lut<T>(k, s->order[iv], s->ncoef[iv], td.lut_m[iv], td.lut_scale[iv], td.lut_steps[iv], lut);
     }
     if ((int)tab.size() != d.tab_len) return fail(BSK_ERR_INVALID, "internal: axis table size changed");
+    if ((int)lut.size() != td.lut_len) return fail(BSK_ERR_INVALID, "internal: bucket table size changed");
     HIPCHK(hipSetDevice(s->device));
     if (d.tab_len) HIPCHK(hipMemcpy(s->tab, tab.data(), sizeof(T) * tab.size(), hipMemcpyHostToDevice));
+    if (td.lut_len) HIPCHK(hipMemcpy(s->lut, lut.data(), sizeof(unsigned) * lut.size(), hipMemcpyHostToDevice));
     if (d.coef_len) HIPCHK(hipMemcpy(s->coef, coefs, sizeof(T) * (size_t)d.coef_len, hipMemcpyHostToDevice));
     return BSK_OK;
 }
@@ -143,6 +200,16 @@ static bsk_status init_desc(bsk_spline s)
     if (tlen > 0x7fffffffLL) return fail(BSK_ERR_UNSUPPORTED, "knot table too large");
     d.tab_len = (int)tlen;
     d.coef_len = (int)(clen * s->nDep);
+    TileDesc<T> &td = tile_of<T>(s);
+    memset(&td, 0, sizeof(td));
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        td.lut_m[iv] = lut_buckets(s->order[iv], s->ncoef[iv]);
+        td.lut_len += td.lut_m[iv];
+    }
+    auto up16 = [](size_t b) { return (unsigned)((b + 15) & ~(size_t)15); };
+    td.tab_bytes = up16(sizeof(T) * (size_t)d.tab_len);
+    td.lut_bytes = up16(sizeof(unsigned) * (size_t)td.lut_len);
+    td.coef_bytes = up16(sizeof(T) * (size_t)d.coef_len);
     return BSK_OK;
 }
 
@@ -202,6 +269,7 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
         if (s->tab) (void)hipFree(s->tab);
         if (s->coef) (void)hipFree(s->coef);
         if (s->bad) (void)hipFree(s->bad);
+        if (s->lut) (void)hipFree(s->lut);
         delete s;
     };
 #define HIPCHK_C(expr)                                                                        \
@@ -221,7 +289,9 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
                                                   : (size_t)64 * 1024);
     HIPCHK_C(hipMalloc(&s->tab, std::max<size_t>(16, s->esize * (size_t)tab_len)));
     HIPCHK_C(hipMalloc(&s->coef, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+    HIPCHK_C(hipMalloc((void **)&s->lut, std::max<size_t>(16, sizeof(unsigned) * (size_t)(dtype == BSK_F32 ? s->t32.lut_len : s->t64.lut_len))));
     HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
+    if (const char *v = getenv("BSK_VARIANT")) s->variant = atoi(v);
     HIPCHK_C(hipMemset(s->bad, 0xff, sizeof(unsigned long long)));
 #undef HIPCHK_C
     st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
@@ -246,6 +316,7 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     if (s->tab) (void)hipFree(s->tab);
     if (s->coef) (void)hipFree(s->coef);
     if (s->bad) (void)hipFree(s->bad);
+    if (s->lut) (void)hipFree(s->lut);
     s->in_ws.release();
     s->out_ws.release();
     s->aux_ws.release();
@@ -347,6 +418,45 @@ static bsk_status launch_eval_generic(bsk_spline s, const Params<T> &prm, long l
     return BSK_OK;
 }
 
+// Tile kernels (bsk_tile.hpp): whole table image in LDS.  Returns the LDS bytes needed, or 0
+// when the image (plus, for perm, the staging area) does not fit.
+template <typename T>
+static size_t tile_lds_bytes(bsk_spline s, bool perm)
+{
+    const TileDesc<T> &td = tile_of<T>(s);
+    size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes;
+    if (perm)
+        b += (size_t)s->nInd * TILE * sizeof(T) + (size_t)s->nInd * TILE * 2 + 2 * TILE * 2 +
+             (NCLASS + 2 * (NCLASS + 1) + 2) * sizeof(int) + (size_t)s->nDep * TILE * sizeof(T);
+    for (int iv = 0; iv < s->nInd; ++iv)
+        if (s->ncoef[iv] > 65535) return 0;
+    return b <= s->lds_max ? b : 0;
+}
+
+template <typename T, int NIND, int O>
+static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Params<T> &prm, long long n, T *out,
+                                   long long ostride, const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const TileDesc<T> &td = tile_of<T>(s);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    const long long ntiles = (n + TILE - 1) / TILE;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
+    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
+    if (perm) {
+        HIPCHK(allow_lds(eval_tile<T, NIND, O, true>, lds));
+        hipLaunchKernelGGL((eval_tile<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad);
+    } else {
+        HIPCHK(allow_lds(eval_tile<T, NIND, O, false>, lds));
+        hipLaunchKernelGGL((eval_tile<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
 // Fast-path coverage: nInd 1..3, one common order 1..6.
 static bool has_fixed_path(bsk_spline s)
 {
@@ -369,6 +479,21 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
                                 const Wrt &w, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s) && s->variant != 1) {
+        // table image fits in LDS: tile kernel; bank permutation pays once a tile is full and
+        // the window is at least a surface's
+        const bool want_perm = s->variant == 3 || (s->variant == 0 && s->nInd >= 2 && n >= 4 * TILE);
+        size_t lds = want_perm ? tile_lds_bytes<T>(s, true) : 0;
+        bool perm = lds != 0;
+        if (!perm) lds = tile_lds_bytes<T>(s, false);
+        if (lds != 0) {
+#define CALL_TILE(NIND, O) launch_eval_tile<T, NIND, O>(s, perm, lds, prm, n, out, ostride, w, st)
+            if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_TILE) }
+            else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_TILE) }
+            else { BSK_ORDER_SWITCH(3, CALL_TILE) }
+#undef CALL_TILE
+        }
+    }
     if (has_fixed_path(s)) {
         const Plan p = make_plan<T>(s, n);
 #define CALL_EVAL(NIND, O) launch_eval_fixed<T, NIND, O>(s, p, prm, n, out, ostride, w, st)
