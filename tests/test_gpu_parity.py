@@ -320,3 +320,34 @@ def test_empty_and_ragged():
         out = t.evaluate([c.points[0][:n], c.points[1][:n]])
         orc, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, [0, 0], [c.points[0][:n], c.points[1][:n]])
         assert np.abs(out - orc).max() <= 1e-12 * _scale(orc)
+
+
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_kernel_variants(variant, golden_parity, monkeypatch):
+    """BSK_VARIANT pins the kernel family (1 simple, 2 LDS tile, 3 LDS tile + bank-class
+    permutation); every family must meet the same parity bar on its own."""
+    monkeypatch.setenv("BSK_VARIANT", variant)
+    for name in ("cfg1_curve", "cfg2_bicubic", "cfg2_bicubic_nonuniform", "bezier_patch_f32", "curve_order5",
+                 "volume_o4_d1", "surface_o7x3_d6", "curve_f32", "curve_many_knots"):
+        c = CASES[name]
+        t = _tables(c)
+        for w in c.wrts:
+            ref = golden_parity[f"{name}/wrt_" + "_".join(map(str, w))]
+            out = t.evaluate(c.points, list(w))
+            assert np.abs(out - ref).max() <= _tol(c) * _scale(ref), (variant, name, w)
+    # a multi-tile batch with a ragged tail, against the oracle
+    c = CASES["cfg2_bicubic_nonuniform"]
+    rng = np.random.default_rng(5)
+    n = 7 * 1024 + 333
+    dom = [(k[o - 1], k[nc]) for k, o, nc in zip(c.knots, c.order, c.nCoef)]
+    pts = [lo + (hi - lo) * rng.random(n) for lo, hi in dom]
+    t = _tables(c)
+    for w in ([0, 0], [1, 2]):
+        out = t.evaluate(pts, w)
+        orc, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, w, pts)
+        assert np.abs(out - orc).max() <= 1e-12 * _scale(orc), (variant, w)
+    bad = [p.copy() for p in pts]
+    bad[0][5000] = dom[0][1] + 1.0
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 5000
