@@ -482,7 +482,7 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
     if (has_fixed_path(s) && s->variant != 1) {
         // table image fits in LDS: tile kernel; bank permutation pays once a tile is full and
         // the window is at least a surface's
-        const bool want_perm = s->variant == 3 || (s->variant == 0 && s->nInd >= 2 && n >= 4 * TILE);
+        const bool want_perm = s->variant == 3;   // measured slower than the plain tile kernel so far (profiles/)
         size_t lds = want_perm ? tile_lds_bytes<T>(s, true) : 0;
         bool perm = lds != 0;
         if (!perm) lds = tile_lds_bytes<T>(s, false);

@@ -1,0 +1,139 @@
+"""
+Multi-GPU evaluation: the point batch is sharded across ranks (one process per GPU,
+``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm), every rank evaluates its
+contiguous shard with its own replica of the spline tables (<= 1 MB), and - only when the
+caller asks for the full result everywhere - the shards are all-gathered.
+
+The reference has no distributed code at all; points are independent, so the
+path shards with NO data-path collective.  ``gather=True`` adds the one exchange step
+BASELINE.json names (all-gather of results): one ``all_gather_into_tensor`` per dependent
+variable, each rank contributing ``ceil(N / world)`` values, written straight into the
+final SoA layout.  Over 7 xGMI links (~153 GB/s each) that gather costs several times the
+kernel, so leave results sharded (``gather=False``) when the consumer is
+sharded too.
+"""
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous shard [start, stop) of rank ``rank``: ceil(n / world) points per rank,
+    the tail ranks may be short or empty."""
+    chunk = -(-int(n) // int(world)) if n > 0 else 0
+    start = min(rank * chunk, n)
+    return start, min(start + chunk, n)
+
+
+def shard_chunk(n, world):
+    return -(-int(n) // int(world)) if n > 0 else 0
+
+
+class ShardedEvaluator:
+    """Sharded ``evaluate`` / ``derivative`` / ``jacobian`` of one spline.
+
+    ``spline``      a ``bspy_amd.Spline`` (or anything with its attributes)
+    ``group``       torch.distributed process group (default: WORLD)
+    ``local_eval``  optional ``f(op, points, wrt) -> array (rows, m)`` replacing the local
+                    GPU evaluation (tests inject a CPU checker under gloo); ``op`` is
+                    "evaluate" or "jacobian".  Default: this rank's DeviceSpline.
+    """
+
+    def __init__(self, spline, group=None, local_eval=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.spline = spline
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local_eval = local_eval
+        self.device = device
+
+    # -- local compute -------------------------------------------------------------------
+    def _local(self, op, pts, wrt):
+        """Returns (result or None, local index of the first out-of-domain point or -1)."""
+        if self.local_eval is not None:
+            return self.local_eval(op, pts, wrt)
+        from . import _native as nv
+        from . import _spline_evaluation as ev
+        tables = ev.device_tables(self.spline, self.device)
+        try:
+            if ev._is_torch(pts[0]):
+                if op == "jacobian":
+                    res = tables.jacobian_device(pts, check=False).view(-1, pts[0].numel())
+                else:
+                    res = tables.evaluate_device(pts, wrt, check=False)
+                tables.domain_status()          # the kernel's own inclusive-domain check
+            elif op == "jacobian":
+                res = tables.jacobian(pts).reshape(-1, len(pts[0]))
+            else:
+                res = tables.evaluate(pts, wrt)
+        except nv.DomainError as e:
+            return None, e.index
+        return res, -1
+
+    # -- public API ----------------------------------------------------------------------
+    def evaluate(self, points, wrt=None, gather=True, sharded_input=False, total=None):
+        return self._run("evaluate", points, wrt, gather, sharded_input, total)
+
+    def derivative(self, with_respect_to, points, gather=True, sharded_input=False, total=None):
+        return self._run("evaluate", points, [int(w) for w in with_respect_to], gather, sharded_input, total)
+
+    def jacobian(self, points, gather=True, sharded_input=False, total=None):
+        return self._run("jacobian", points, None, gather, sharded_input, total)
+
+    def _run(self, op, points, wrt, gather, sharded_input, total):
+        """points: nInd 1-D arrays/tensors.  With ``sharded_input`` each rank passes only its
+        own shard (``total`` = global point count, shards as ``shard_bounds``); otherwise
+        every rank passes the full batch and takes its slice.
+        Returns (rows, N) if gather else this rank's (rows, n_local); rows = nDep
+        (evaluate/derivative) or nDep * nInd (jacobian, row = d * nInd + j)."""
+        import torch
+        nind = self.spline.nInd
+        if len(points) != nind:
+            raise ValueError(f"Incorrect number of parameter values: {len(points)}")
+        if sharded_input:
+            if total is None:
+                raise ValueError("total (global point count) is required with sharded_input")
+            n = int(total)
+            start, stop = shard_bounds(n, self.world, self.rank)
+            local = list(points)
+            if len(local[0]) != stop - start:
+                raise ValueError(f"rank {self.rank} must pass {stop - start} points, got {len(local[0])}")
+        else:
+            n = len(points[0])
+            start, stop = shard_bounds(n, self.world, self.rank)
+            local = [p[start:stop] for p in points]
+        res, bad_local = self._local(op, local, wrt)
+
+        # the reference raises for the first offending point; make every rank agree on it
+        import_max = np.iinfo(np.int64).max
+        bad = torch.tensor([start + bad_local if bad_local >= 0 else import_max], dtype=torch.int64)
+        is_t = hasattr(res, "is_cuda") or (res is None and hasattr(local[0], "is_cuda"))
+        dev = local[0].device if hasattr(local[0], "is_cuda") else None
+        if self.world > 1:
+            if dev is not None and dev.type == "cuda":
+                bad = bad.to(dev)
+            self.dist.all_reduce(bad, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(bad.item()) != import_max:
+            idx = int(bad.item())
+            where = ""
+            if not sharded_input:
+                pt = [float(p[idx]) for p in points]
+                where = f" {np.atleast_1d(pt)}"
+            raise ValueError(f"Spline evaluation outside domain:{where} (flat index {idx})")
+        if not gather or self.world == 1:
+            return res
+
+        # all-gather: one collective per output row, written in place into the (rows, N) result
+        chunk = shard_chunk(n, self.world)
+        rows = res.shape[0]
+        t = res if is_t else torch.from_numpy(np.ascontiguousarray(res))
+        full = torch.empty((rows, self.world * chunk), dtype=t.dtype, device=t.device)
+        if t.shape[1] != chunk:          # short tail shard: pad to the common chunk
+            pad = torch.zeros((rows, chunk), dtype=t.dtype, device=t.device)
+            pad[:, :t.shape[1]] = t
+            t = pad
+        t = t.contiguous()
+        for r in range(rows):
+            self.dist.all_gather_into_tensor(full[r], t[r], group=self.group)
+        full = full[:, :n]
+        return full if is_t else full.numpy()

@@ -1,0 +1,215 @@
+"""
+CPU-only tests of the host logic: constructor semantics and error strings against the
+reference's recorded behaviour, dispatch helpers, the C-ABI library's exported symbols,
+the shard plan, and the multi-rank path under gloo (world_size 2) with the CPU oracle
+injected as the per-rank evaluator.  No GPU compute is attempted here.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import bspy_amd
+from bspy_amd import Spline
+from bspy_amd import _native, _spline_evaluation as ev
+from bspy_amd.sharding import shard_bounds, shard_chunk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bspy_amd.h")).read()
+    declared = set(re.findall(r"\b(bsk_[a-z_]+)\s*\(", header))
+    declared -= {"bsk_status"}
+    assert declared == set(_native.SYMBOLS)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _native.lib().bsk_version() == 1
+    # constants mirrored in Python match the header
+    assert int(re.search(r"#define BSK_MAX_NIND (\d+)", header).group(1)) == _native.BSK_MAX_NIND
+    assert int(re.search(r"#define BSK_MAX_ORDER (\d+)", header).group(1)) == _native.BSK_MAX_ORDER
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU (this container) every compute entry point raises: nothing is computed
+    on the host behind the user's back."""
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    s = Spline(1, 1, [4], [4], [[0, 0, 0, 0, 1, 1, 1, 1.0]], [[0.0, 1, 2, 3]])
+    with pytest.raises(bspy_amd.BskError):
+        s(0.5)
+    with pytest.raises(bspy_amd.BskError):
+        s(np.linspace(0, 1, 10))
+    with pytest.raises(bspy_amd.BskError):
+        s.jacobian([0.5])
+    with pytest.raises(bspy_amd.BskError):
+        Spline.bspline_values(None, np.array([0, 0, 1, 1.0]), 2, 0.5)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libbspy_amd.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_product_does_not_import_the_oracle():
+    out = subprocess.run(["grep", "-rIl", "-E", r"^\s*(import|from)\s+oracle", os.path.join(ROOT, "bspy_amd")],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", out
+
+
+def test_constructor_matches_reference(golden_api):
+    a = golden_api
+    k = [0, 0, 0, 0, .3, .3, .7, 1, 1, 1, 1]
+
+    def err(f):
+        try:
+            f()
+        except Exception as e:  # noqa: BLE001
+            return [type(e).__name__, str(e)]
+        return None
+
+    got = {
+        "nInd": err(lambda: Spline(-1, 1, [], [], [], [])),
+        "order": err(lambda: Spline(1, 1, [4, 4], [4], [k], [[0, 1, 2, 3]])),
+        "nCoef": err(lambda: Spline(1, 1, [4], [4, 4], [k], [[0, 1, 2, 3]])),
+        "nknots": err(lambda: Spline(1, 1, [4], [4], [k], [[0.0, 1, 2, 3]])),
+        "knots_len": err(lambda: Spline(1, 1, [4], [4], [k, k], [[0.0, 1, 2, 3]])),
+        "knot_order": err(lambda: Spline(1, 1, [4], [4], [[0, 0, 0.5, 0.2, 1, 1, 1, 1]], [[0.0, 1, 2, 3]])),
+        "knot_mult": err(lambda: Spline(1, 1, [4], [5], [[0, 0, 0, 0, 0, 1, 1, 1, 1.0]], [[0.0, 1, 2, 3, 4]])),
+        "coefs_len": err(lambda: Spline(1, 2, [4], [4], [[0, 0, 0, 0, 1, 1, 1, 1.0]], [[0.0, 1, 2]])),
+    }
+    assert got == a["err_ctor"]
+    k2 = [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]]
+    s3 = Spline(2, 3, [3, 4], [4, 5], k2, np.arange(60.0).reshape(20, 3))
+    assert s3.coefs.shape == (3, 4, 5)
+    assert np.array_equal(np.ascontiguousarray(s3.coefs), np.array(a["flat_coefs"]))
+    per = [np.arange(20.0).reshape(5, 4) + 100 * d for d in range(3)]
+    s4 = Spline(2, 3, [3, 4], [4, 5], k2, per)
+    assert np.array_equal(np.ascontiguousarray(s4.coefs), np.array(a["perdep_coefs"]))
+    assert np.array_equal(s4.domain(), np.array(a["domain"]))
+    s0 = Spline(0, 2, [], [], [], [1.5, 2.5])
+    assert np.asarray(s0.evaluate()).tolist() == a["nind0_eval"]
+    assert np.asarray(s0.derivative([])).tolist() == a["nind0_deriv"]
+    # dtype rules: float32 stays float32, integers are promoted (documented deviation)
+    f = Spline(1, 1, [2], [2], [np.array([0, 0, 1, 1], np.float32)], np.array([[0, 1]], np.float32))
+    assert f.knots[0].dtype == np.float32 and f.coefs.dtype == np.float32 and ev.compute_dtype(f) == np.float32
+    i = Spline(1, 1, [2], [2], [[0, 0, 1, 1]], [[0, 1]])
+    assert i.knots[0].dtype == np.float64 and i.coefs.dtype == np.float64
+    m = Spline(1, 1, [2], [2], [np.array([0, 0, 1, 1], np.float32)], np.array([[0, 1]], np.float64))
+    assert ev.compute_dtype(m) == np.float64
+    assert isinstance(s4.metadata, dict) and Spline(1, 1, [2], [2], [[0, 0, 1, 1.0]], [[0, 1.0]], {"Name": "x"}).metadata == {"Name": "x"}
+
+
+def test_arity_and_kwargs_errors():
+    s2 = Spline(2, 3, [3, 4], [4, 5], [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]],
+                np.arange(60.0).reshape(3, 4, 5))
+    with pytest.raises(ValueError, match="Incorrect number of parameter values: 1"):
+        s2.evaluate([0.1])
+    with pytest.raises(ValueError, match="Incorrect number of parameter values: 3"):
+        s2.jacobian([0.1, 0.2, 0.3])
+    with pytest.raises(TypeError, match="ufunc keyword"):
+        s2(np.zeros(4), np.zeros(4), where=np.ones(4, bool))
+
+
+def test_grid_detection():
+    u, v, w = np.zeros(5), np.zeros(7), np.zeros(3)
+    assert ev._grid_axes([u[:, None], v[None, :]], (5, 7)) == [0, 1]
+    assert ev._grid_axes([u[None, :], v[:, None]], (7, 5)) == [1, 0]
+    assert ev._grid_axes([u[:, None, None], v[None, :, None], w[None, None, :]], (5, 7, 3)) == [0, 1, 2]
+    assert ev._grid_axes([u, np.zeros(5)], (5,)) is None                      # same axis twice: not a grid
+    assert ev._grid_axes([np.zeros((5, 7)), v[None, :]], (5, 7)) is None      # 2-D parameter array
+    assert ev._grid_axes([u[:, None], np.float64(0.5)], (5, 1)) == [0, None]  # scalar second variable
+    assert ev._grid_axes([u[:, None], np.zeros((1, 1))], (5, 7)) is None      # axis 1 of the result driven by nobody
+
+
+def test_shard_plan():
+    for n in (0, 1, 7, 8, 9, 1000, 10_000_000):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                a, b = shard_bounds(n, world, r)
+                assert 0 <= a <= b <= n and b - a <= shard_chunk(n, world)
+                covered.extend(range(a, b) if n < 2000 else [])
+                if r:
+                    assert a == shard_bounds(n, world, r - 1)[1]
+            assert shard_bounds(n, world, world - 1)[1] == n
+            if n < 2000:
+                assert covered == list(range(n))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import cases, oracle
+from bspy_amd import Spline
+from bspy_amd.sharding import ShardedEvaluator, shard_bounds
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+rank, world = dist.get_rank(), dist.get_world_size()
+c = {x.name: x for x in cases.parity_cases()}["cfg2_bicubic"]
+s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+
+def cpu_checker(op, pts, wrt):      # tests may use the oracle; the product path never does
+    if op == "jacobian":
+        out, bad = oracle.c_jacobian(c.order, c.nCoef, c.knots, c.coefs, pts)
+        return (None, bad) if bad >= 0 else (out.reshape(-1, len(pts[0])), -1)
+    out, bad = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, wrt or [0, 0], pts)
+    return (None, bad) if bad >= 0 else (out, -1)
+
+sh = ShardedEvaluator(s, local_eval=cpu_checker)
+n = 1001                                            # not divisible by the world size: ragged tail shard
+pts = [p[:n] for p in c.points]
+full, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, [0, 0], pts)
+got = sh.evaluate(pts)
+assert got.shape == full.shape and np.array_equal(got, full), "gathered evaluate"
+a, b = shard_bounds(n, world, rank)
+loc = sh.evaluate(pts, gather=False)
+assert np.array_equal(loc, full[:, a:b]), "sharded evaluate"
+d = sh.derivative([1, 0], [p[a:b] for p in pts], sharded_input=True, total=n)
+fd, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, [1, 0], pts)
+assert np.array_equal(d, fd), "pre-sharded derivative"
+j = sh.jacobian(pts)
+fj, _ = oracle.c_jacobian(c.order, c.nCoef, c.knots, c.coefs, pts)
+assert np.array_equal(j, fj.reshape(-1, n)), "gathered jacobian"
+bad = [p.copy() for p in pts]
+bad[1][900] = 7.0                                   # lives in the last rank's shard
+bad[0][950] = -3.0
+try:
+    sh.evaluate(bad)
+    raise SystemExit("no error raised")
+except ValueError as e:
+    assert "outside domain" in str(e) and "flat index 900" in str(e), str(e)   # every rank reports the first offender
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_evaluator_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + os.getpid() % 2000
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r), "2"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out}"
+        assert f"rank {r} ok" in out
