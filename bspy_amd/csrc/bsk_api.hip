@@ -9,6 +9,7 @@
 
 #include "bsk_kernels.hpp"
 #include "bsk_tile.hpp"
+#include "bsk_stream.hpp"
 
 using namespace bsk;
 
@@ -68,7 +69,7 @@ struct bsk_spline_s {
     void *tab = nullptr;     // device axis table
     void *coef = nullptr;    // device coefficients
     unsigned *lut = nullptr; // device span-search bucket tables
-    int variant = 0;         // BSK_VARIANT override: 0 auto, 1 simple, 2 tile, 3 tile + bank permutation
+    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -444,7 +445,17 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
     const long long ntiles = (n + TILE - 1) / TILE;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
-    if (perm) {
+    bool deriv = false;
+    for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
+    if ((s->variant == 0 || s->variant == 4) && deriv) {
+        HIPCHK(allow_lds(eval_stream<T, NIND, O, true>, lds));
+        hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad);
+    } else if (s->variant == 0 || s->variant == 4) {
+        HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
+        hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad);
+    } else if (perm) {
         HIPCHK(allow_lds(eval_tile<T, NIND, O, true>, lds));
         hipLaunchKernelGGL((eval_tile<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
@@ -474,12 +485,25 @@ static bool has_fixed_path(bsk_spline s)
         default: break;                                     \
     }
 
+// The asm-LDS kernels (tile / stream) cover orders 1..5: at order 6 their register windows
+// (36-value slabs, 20 table values per variable) no longer fit without spilling, which those
+// kernels must never do (check_spills.py); order 6 runs on eval_fixed.
+#define BSK_ORDER_SWITCH5(NIND, CALL)                       \
+    switch (s->order[0]) {                                  \
+        case 1: return CALL(NIND, 1);                       \
+        case 2: return CALL(NIND, 2);                       \
+        case 3: return CALL(NIND, 3);                       \
+        case 4: return CALL(NIND, 4);                       \
+        case 5: return CALL(NIND, 5);                       \
+        default: break;                                     \
+    }
+
 template <typename T>
 static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
                                 const Wrt &w, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
-    if (has_fixed_path(s) && s->variant != 1) {
+    if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         // table image fits in LDS: tile kernel; bank permutation pays once a tile is full and
         // the window is at least a surface's
         const bool want_perm = s->variant == 3;   // measured slower than the plain tile kernel so far (profiles/)
@@ -488,9 +512,9 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         if (!perm) lds = tile_lds_bytes<T>(s, false);
         if (lds != 0) {
 #define CALL_TILE(NIND, O) launch_eval_tile<T, NIND, O>(s, perm, lds, prm, n, out, ostride, w, st)
-            if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_TILE) }
-            else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_TILE) }
-            else { BSK_ORDER_SWITCH(3, CALL_TILE) }
+            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_TILE) }
+            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_TILE) }
+            else { BSK_ORDER_SWITCH5(3, CALL_TILE) }
 #undef CALL_TILE
         }
     }

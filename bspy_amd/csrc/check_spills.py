@@ -1,0 +1,17 @@
+"""Build-time guard: the kernels that read LDS through inline asm (eval_tile, eval_stream)
+must not use scratch: a spilled asm destination would be stored before its data arrived.
+Usage: python check_spills.py <resource-usage log>"""
+import re
+import sys
+
+log = open(sys.argv[1]).read()
+bad = []
+for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", log, re.S):
+    name, scratch = m.group(1), int(m.group(2))
+    if ("eval_tile" in name or "eval_stream" in name or "jac_stream" in name or "eval_perm" in name) and scratch:
+        bad.append((name, scratch))
+if bad:
+    for name, scratch in bad:
+        print(f"SPILL in asm-LDS kernel {name}: {scratch} bytes/lane", file=sys.stderr)
+    sys.exit(1)
+print("no scratch in asm-LDS kernels")
