@@ -69,7 +69,8 @@ struct bsk_spline_s {
     void *tab = nullptr;     // device axis table
     void *coef = nullptr;    // device coefficients
     unsigned *lut = nullptr; // device span-search bucket tables
-    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream
+    int dbg = 0;             // BSK_DEBUG: timing-only ablation bits of eval_perm (results wrong)
+    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream, 5 perm (pipelined bank permutation)
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -293,6 +294,7 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
     HIPCHK_C(hipMalloc((void **)&s->lut, std::max<size_t>(16, sizeof(unsigned) * (size_t)(dtype == BSK_F32 ? s->t32.lut_len : s->t64.lut_len))));
     HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
     if (const char *v = getenv("BSK_VARIANT")) s->variant = atoi(v);
+    if (const char *v = getenv("BSK_DEBUG")) s->dbg = atoi(v);
     HIPCHK_C(hipMemset(s->bad, 0xff, sizeof(unsigned long long)));
 #undef HIPCHK_C
     st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
@@ -425,13 +427,52 @@ template <typename T>
 static size_t tile_lds_bytes(bsk_spline s, bool perm)
 {
     const TileDesc<T> &td = tile_of<T>(s);
-    size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes;
+    size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes + TILE * sizeof(unsigned);   // + rank-rotation counters
     if (perm)
         b += (size_t)s->nInd * TILE * sizeof(T) + (size_t)s->nInd * TILE * 2 + 2 * TILE * 2 +
              (NCLASS + 2 * (NCLASS + 1) + 2) * sizeof(int) + (size_t)s->nDep * TILE * sizeof(T);
     for (int iv = 0; iv < s->nInd; ++iv)
         if (s->ncoef[iv] > 65535) return 0;
     return b <= s->lds_max ? b : 0;
+}
+
+// eval_perm staging: parameters, packed spans, slot and overflow lists, class counters, all
+// double buffered by tile parity.  Needs every nCoef <= 1023 (10-bit packed spans).
+template <typename T>
+static size_t perm_lds_bytes(bsk_spline s)
+{
+    const TileDesc<T> &td = tile_of<T>(s);
+    for (int iv = 0; iv < s->nInd; ++iv)
+        if (s->ncoef[iv] > 1023) return 0;
+    if (s->nInd > 3) return 0;
+    const size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes + 2 * (size_t)s->nInd * TILE * sizeof(T) +
+                     2 * TILE * sizeof(unsigned) + 4 * TILE * sizeof(unsigned short) + 2 * NCLASS * sizeof(int);
+    return b <= s->lds_max ? b : 0;
+}
+
+template <typename T, int NIND, int O>
+static bsk_status launch_eval_perm(bsk_spline s, size_t lds, const Params<T> &prm, long long n, T *out,
+                                   long long ostride, const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const TileDesc<T> &td = tile_of<T>(s);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    const long long ntiles = (n + TILE - 1) / TILE;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu));
+    bool deriv = false;
+    for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
+    if (deriv) {
+        HIPCHK(allow_lds(eval_perm<T, NIND, O, true>, lds));
+        hipLaunchKernelGGL((eval_perm<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad, s->dbg);
+    } else {
+        HIPCHK(allow_lds(eval_perm<T, NIND, O, false>, lds));
+        hipLaunchKernelGGL((eval_perm<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+                           n, out, ostride, w, s->bad, s->dbg);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
 }
 
 template <typename T, int NIND, int O>
@@ -449,11 +490,11 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
     for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
     if ((s->variant == 0 || s->variant == 4) && deriv) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, true>, lds));
-        hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+        hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     } else if (s->variant == 0 || s->variant == 4) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
-        hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+        hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     } else if (perm) {
         HIPCHK(allow_lds(eval_tile<T, NIND, O, true>, lds));
@@ -503,6 +544,16 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
                                 const Wrt &w, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s) && s->order[0] <= 5 && s->variant == 5) {
+        const size_t plds = perm_lds_bytes<T>(s);
+        if (plds != 0) {
+#define CALL_PERM(NIND, O) launch_eval_perm<T, NIND, O>(s, plds, prm, n, out, ostride, w, st)
+            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_PERM) }
+            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_PERM) }
+            else { BSK_ORDER_SWITCH5(3, CALL_PERM) }
+#undef CALL_PERM
+        }
+    }
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         // table image fits in LDS: tile kernel; bank permutation pays once a tile is full and
         // the window is at least a surface's
