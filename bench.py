@@ -99,11 +99,25 @@ def main():
     out = torch.empty((ndep, nind, n) if args.op == "jacobian" else (ndep, n), dtype=torch.float64, device=dev)
     wrt = [1, 1] if args.op == "derivative" else None
 
+    # One step = one C-ABI call on the current stream.  The ctypes arguments are built once so
+    # the host side of a step is a single foreign call (the Python wrappers' tensor checks
+    # cost more than the kernel's launch gap and would make the loop host-bound).
+    import ctypes
+    from bspy_amd import _native as nv
+    lib = nv.lib()
+    uvw_ptrs = nv.ptr_array([u.data_ptr(), v.data_ptr()])
+    wrt_arr = nv.int_array(wrt) if wrt is not None else None
+    stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out_ptr = ctypes.c_void_p(out.data_ptr())
+    handle = tables._handle
+
     def step():
         if args.op == "jacobian":
-            tables.jacobian_device([u, v], out=out, check=False)
+            st = lib.bsk_jacobian(handle, uvw_ptrs, n, nv.BSK_DEVICE, out_ptr, stream_ptr, None)
         else:
-            tables.evaluate_device([u, v], wrt, out=out, check=False)
+            st = lib.bsk_evaluate(handle, wrt_arr, uvw_ptrs, n, nv.BSK_DEVICE, out_ptr, stream_ptr, None)
+        if st != 0:
+            nv.check(st)
 
     def barrier():
         if dist is not None:

@@ -5,11 +5,13 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "bsk_kernels.hpp"
 #include "bsk_tile.hpp"
 #include "bsk_stream.hpp"
+#include "bsk_surface.hpp"
 
 using namespace bsk;
 
@@ -70,7 +72,7 @@ struct bsk_spline_s {
     void *coef = nullptr;    // device coefficients
     unsigned *lut = nullptr; // device span-search bucket tables
     int dbg = 0;             // BSK_DEBUG: timing-only ablation bits of eval_perm (results wrong)
-    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream, 5 perm (pipelined bank permutation)
+    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream, 5 perm (pipelined bank permutation), 6 surface2 (two points per lane)
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -359,12 +361,21 @@ static Plan make_plan(bsk_spline s, long long n)
     return p;
 }
 
+// Raise a kernel's dynamic-LDS limit above 64 KiB.  hipFuncSetAttribute is a driver call
+// (tens of microseconds): it is issued once per kernel, device and size, not per launch.
 template <typename K>
 static hipError_t allow_lds(K kernel, size_t bytes)
 {
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
+    static thread_local std::vector<std::tuple<const void *, int, size_t>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    for (const auto &e : done)
+        if (std::get<0>(e) == fn && std::get<1>(e) == dev && std::get<2>(e) >= bytes) return hipSuccess;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err == hipSuccess) done.emplace_back(fn, dev, bytes);
+    return err;
 }
 
 template <typename T, int NIND, int O>
@@ -488,14 +499,71 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     bool deriv = false;
     for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
+    if constexpr (NIND == 2) {
+        // plain-C++ surface kernel, one (variant 7) or two (variant 8) points per lane
+        const bool aligned2 = (((uintptr_t)prm.p[0] | (uintptr_t)prm.p[1] | (uintptr_t)out) & 15) == 0 &&
+                              (ostride * (long long)sizeof(T)) % 16 == 0;
+        if (s->variant == 7 || (s->variant == 8 && !aligned2)) {
+            const long long nt1 = (n + 1023) / 1024;
+            const int g1 = (int)std::max<long long>(1, std::min<long long>(nt1, (long long)s->num_cu * per_cu));
+            if (deriv) {
+                HIPCHK(allow_lds(eval_surface<T, O, true, 1>, lds));
+                hipLaunchKernelGGL((eval_surface<T, O, true, 1>), dim3(g1), dim3(1024), lds, st, d, td, tab, s->lut, coef,
+                                   prm, n, out, ostride, w, s->bad);
+            } else {
+                HIPCHK(allow_lds(eval_surface<T, O, false, 1>, lds));
+                hipLaunchKernelGGL((eval_surface<T, O, false, 1>), dim3(g1), dim3(1024), lds, st, d, td, tab, s->lut, coef,
+                                   prm, n, out, ostride, w, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+        if (s->variant == 8) {
+            const long long nt2 = ((n + 1) / 2 + 511) / 512;
+            const int g2 = (int)std::max<long long>(1, std::min<long long>(nt2, (long long)s->num_cu * per_cu));
+            if (deriv) {
+                HIPCHK(allow_lds(eval_surface<T, O, true, 2>, lds));
+                hipLaunchKernelGGL((eval_surface<T, O, true, 2>), dim3(g2), dim3(512), lds, st, d, td, tab, s->lut, coef,
+                                   prm, n, out, ostride, w, s->bad);
+            } else {
+                HIPCHK(allow_lds(eval_surface<T, O, false, 2>, lds));
+                hipLaunchKernelGGL((eval_surface<T, O, false, 2>), dim3(g2), dim3(512), lds, st, d, td, tab, s->lut, coef,
+                                   prm, n, out, ostride, w, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
+    if constexpr (NIND == 2 && (O == 2 || O == 4)) {
+        // two adjacent points per lane with 16-byte loads/stores: needs aligned rows
+        const bool aligned = (((uintptr_t)prm.p[0] | (uintptr_t)prm.p[1] | (uintptr_t)out) & 15) == 0 &&
+                             (ostride * (long long)sizeof(T)) % 16 == 0;
+        if (s->variant == 6 && aligned) {
+            constexpr int DEPTH = 4;
+            const long long npairs = (n + 1) / 2;
+            const long long nt2 = (npairs + SURF2_BLOCK - 1) / SURF2_BLOCK;
+            const int grid2 = (int)std::max<long long>(1, std::min<long long>(nt2, (long long)s->num_cu * per_cu));
+            if (deriv) {
+                HIPCHK(allow_lds(eval_surface2<T, O, true, DEPTH>, lds));
+                hipLaunchKernelGGL((eval_surface2<T, O, true, DEPTH>), dim3(grid2), dim3(SURF2_BLOCK), lds, st, d, td, tab,
+                                   s->lut, coef, prm, n, out, ostride, w, s->bad);
+            } else {
+                HIPCHK(allow_lds(eval_surface2<T, O, false, DEPTH>, lds));
+                hipLaunchKernelGGL((eval_surface2<T, O, false, DEPTH>), dim3(grid2), dim3(SURF2_BLOCK), lds, st, d, td, tab,
+                                   s->lut, coef, prm, n, out, ostride, w, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
     if ((s->variant == 0 || s->variant == 4) && deriv) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, true>, lds));
         hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad);
+                           n, out, ostride, w, s->bad, s->dbg);
     } else if (s->variant == 0 || s->variant == 4) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
         hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad);
+                           n, out, ostride, w, s->bad, s->dbg);
     } else if (perm) {
         HIPCHK(allow_lds(eval_tile<T, NIND, O, true>, lds));
         hipLaunchKernelGGL((eval_tile<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
@@ -883,4 +951,30 @@ extern "C" bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void
                                  static_cast<const double *>(u), n, derivative_order, taylor_coefs, knot_in, ix_out,
                                  static_cast<double *>(basis_out));
     return fail(BSK_ERR_INVALID, "dtype must be BSK_F32 or BSK_F64");
+}
+
+// ------------------------------------------------------------------------------------
+// diagnostics
+// ------------------------------------------------------------------------------------
+// Streams u, v -> out (3 rows) with the evaluation kernels' launch geometry; mode 0/1 = 8/16
+// bytes per lane, blocks_per_cu workgroups per CU, lds_bytes of dynamic LDS each.  Device
+// pointers, fp64.  Used by tools/ to measure the memory-side floor; not an evaluation call.
+extern "C" bsk_status bsk_debug_probe(bsk_spline s, int mode, int blocks_per_cu, int threads, int64_t lds_bytes,
+                                      const void *u, const void *v, int64_t n, void *out, void *stream)
+{
+    if (!s || !u || !v || !out) return fail(BSK_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = s->num_cu * std::max(1, blocks_per_cu);
+    if (mode == 0) {
+        HIPCHK(allow_lds(probe_stream<0>, (size_t)lds_bytes));
+        hipLaunchKernelGGL((probe_stream<0>), dim3(grid), dim3(threads), (size_t)lds_bytes, st, static_cast<const double *>(u),
+                           static_cast<const double *>(v), (long long)n, static_cast<double *>(out), (long long)n);
+    } else {
+        HIPCHK(allow_lds(probe_stream<1>, (size_t)lds_bytes));
+        hipLaunchKernelGGL((probe_stream<1>), dim3(grid), dim3(threads), (size_t)lds_bytes, st, static_cast<const double *>(u),
+                           static_cast<const double *>(v), (long long)n, static_cast<double *>(out), (long long)n);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
 }

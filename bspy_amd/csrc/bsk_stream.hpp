@@ -319,8 +319,17 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                                                     const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                     const T *__restrict__ gcoef, const Params<T> prm,
                                                     const long long N, T *__restrict__ out, const long long ostride,
-                                                    const Wrt wrt, unsigned long long *bad)
+                                                    const Wrt wrt, unsigned long long *bad, const int dbg_arg)
 {
+    // dbg: timing-only ablations of the surface path (results wrong), compiled in only with
+    // -DBSK_ABLATE: 1 no coefficient loads, 2 no products / sums, 4 no span search, 8 no
+    // recursion, 16 no rank atomic, 32 no stores
+#ifdef BSK_ABLATE
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned tab_a = (unsigned)(size_t)smem;
     const unsigned lut_a = tab_a + td.tab_bytes;
@@ -346,29 +355,65 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 
-    T un[NIND];
+    // Register ring of the parameters of the next PF iterations: PF x 16 KB of loads in flight
+    // per CU.  With a single load in flight per lane the kernel is bound by HBM latency
+    // (16 KB per CU outstanding ~ 2 TB/s chip-wide), not by anything it computes.
+    constexpr int PF = 1;
+    // d.lo in registers: `cond ? prm[i] : d.lo[iv]` lets hipcc select between the two ADDRESSES
+    // and emit one flat_load (generic address space), which forces s_waitcnt vmcnt(0)
+    // lgkmcnt(0) every iteration - that serialisation, not LDS or HBM bandwidth, dominated
+    // earlier versions of this kernel.
+    T lo_r[NIND];
 #pragma unroll
-    for (int iv = 0; iv < NIND; ++iv) un[iv] = n < N ? prm.p[iv][n] : d.lo[iv];
+    for (int iv = 0; iv < NIND; ++iv) lo_r[iv] = d.lo[iv];
+    T ring[PF][NIND];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            ring[k][iv] = lo_r[iv];
+            if (n + k * stride < N) ring[k][iv] = prm.p[iv][n + k * stride];
+        }
 
     for (; n < N; n += stride) {
         T u[NIND];
         bool outside = false;
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) {
-            u[iv] = un[iv];
-            outside |= (u[iv] < d.lo[iv]) | (u[iv] > d.hi[iv]);
+            u[iv] = ring[0][iv];
+            outside |= (u[iv] < lo_r[iv]) | (u[iv] > d.hi[iv]);
         }
-        {   // next tile's parameters: in flight while this tile is evaluated
-            const long long nn = n + stride;
 #pragma unroll
-            for (int iv = 0; iv < NIND; ++iv) un[iv] = nn < N ? prm.p[iv][nn] : d.lo[iv];
+        for (int k = 0; k + 1 < PF; ++k)
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) ring[k][iv] = ring[k + 1][iv];
+        {
+            const long long nn = n + PF * stride;
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) ring[PF - 1][iv] = lo_r[iv];
+            if (nn < N) {
+#pragma unroll
+                for (int iv = 0; iv < NIND; ++iv) ring[PF - 1][iv] = prm.p[iv][nn];
+            }
         }
         if (outside) record_bad(bad, n);
 
         int ix[NIND];
-        find_spans<T, NIND>(tab_a, lut_a, d, td, steps, u, ix);
+        if (dbg & 4) {
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) ix[iv] = O + (int)(u[iv] * T(d.ncoef[iv] - O));
+        } else {
+            find_spans<T, NIND>(tab_a, lut_a, d, td, steps, u, ix);
+        }
         T b[NIND][O];
-        bases_all<T, NIND, O, DERIV>(tab_a, d, ix, u, wrt, b);
+        if (dbg & 8) {
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv)
+#pragma unroll
+                for (int k = 0; k < O; ++k) b[iv][k] = u[iv] + T(k);
+        } else {
+            bases_all<T, NIND, O, DERIV>(tab_a, d, ix, u, wrt, b);
+        }
         unsigned caddr = coef_a;
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)((ix[iv] - O) * d.cstride[iv + 1]) * (unsigned)sizeof(T);
@@ -377,8 +422,11 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
             int base = 0;
 #pragma unroll
             for (int iv = 0; iv < NIND; ++iv) base += (ix[iv] - O) * d.cstride[iv + 1];
-            s_rc[lane] = 0u;
-            const int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+            int rho = base & (O - 1);
+            if (!(dbg & 16)) {
+                s_rc[lane] = 0u;
+                rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+            }
             T br[O];
             unsigned co[O];
             rotate_basis<T, O>(b[NIND - 1], rho, br, co);
@@ -388,6 +436,37 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                 // (no asm destinations live across other code).
                 const unsigned rstride = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
                 const char *cw = smem + (caddr - tab_a);
+                if (dbg) {
+                    for (int dep = 0; dep < d.nDep; ++dep) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int a = 0; a < O; ++a) {
+#pragma clang fp contract(off)
+                            const char *row = cw + (unsigned)a * rstride;
+                            T v[O];
+#pragma unroll
+                            for (int j = 0; j < O; ++j) {
+                                if (dbg & 1) v[j] = br[j] + T(a + j);
+                                else v[j] = *reinterpret_cast<const T *>(row + co[j]);
+                            }
+                            if (dbg & 2) {
+#pragma unroll
+                                for (int j = 0; j < O; ++j) asm volatile("" :: "v"(v[j]));
+                                acc = v[0];
+                            } else {
+                                T t = T(0);
+                                if constexpr (O == 4)
+                                    t = add_rn<T>(add_rn<T>(mul_rn<T>(v[0], br[0]), mul_rn<T>(v[2], br[2])),
+                                                  add_rn<T>(mul_rn<T>(v[1], br[1]), mul_rn<T>(v[3], br[3])));
+                                else
+                                    t = add_rn<T>(mul_rn<T>(v[0], br[0]), mul_rn<T>(v[1], br[1]));
+                                acc = add_rn<T>(acc, mul_rn<T>(t, b[0][a]));
+                            }
+                        }
+                        if (!(dbg & 32) || acc == T(12345.678)) out[dep * ostride + n] = acc;
+                        cw += dstride;
+                    }
+                }
                 auto one_dep = [&](int dep) {
                     T acc = T(0);
 #pragma unroll
@@ -411,7 +490,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                     out[dep * ostride + n] = acc;
                     cw += dstride;
                 };
-                if (d.nDep == 3) {          // the common case, unrolled so loads run ahead of the sums
+                if (dbg) {
+                } else if (d.nDep == 3) {   // the common case, unrolled so loads run ahead of the sums
                     one_dep(0); one_dep(1); one_dep(2);
                 } else {
                     for (int dep = 0; dep < d.nDep; ++dep) one_dep(dep);
@@ -460,6 +540,12 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                 caddr += dstride;
             }
         }
+        // Consume the prefetched parameters HERE, at the end of the iteration: the wait the
+        // compiler inserts is then vmcnt(<stores issued above>) and leaves this iteration's
+        // stores in flight.  Left to the loop header it becomes vmcnt(0) (the counter state is
+        // merged over the back edge), which exposed every store's latency once per iteration.
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(ring[0][iv]));
     }
 }
 
@@ -525,7 +611,10 @@ __global__ __launch_bounds__(TILE) void eval_perm(const Desc<T> d, const TileDes
     long long tile = blockIdx.x;
     T un[NIND];
 #pragma unroll
-    for (int iv = 0; iv < NIND; ++iv) un[iv] = (tile < ntiles && tile * TILE + tid < N) ? prm.p[iv][tile * TILE + tid] : d.lo[iv];
+    for (int iv = 0; iv < NIND; ++iv) {
+        un[iv] = d.lo[iv];
+        if (tile < ntiles && tile * TILE + tid < N) un[iv] = prm.p[iv][tile * TILE + tid];
+    }
 
     for (int p = 0; tile < ntiles; tile += gridDim.x, p ^= 1) {
         const long long n0 = tile * TILE;
@@ -548,7 +637,11 @@ __global__ __launch_bounds__(TILE) void eval_perm(const Desc<T> d, const TileDes
         {
             const long long nn = (tile + gridDim.x) * TILE + tid;
 #pragma unroll
-            for (int iv = 0; iv < NIND; ++iv) un[iv] = nn < N ? prm.p[iv][nn] : d.lo[iv];
+            for (int iv = 0; iv < NIND; ++iv) un[iv] = u[iv];          // any in-domain value
+            if (nn < N) {
+#pragma unroll
+                for (int iv = 0; iv < NIND; ++iv) un[iv] = prm.p[iv][nn];
+            }
         }
         if (valid && outside) record_bad(bad, n);
         int ix[NIND];
@@ -646,6 +739,196 @@ __global__ __launch_bounds__(TILE) void eval_perm(const Desc<T> d, const TileDes
                     caddr += dstride;
                 }
             }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// eval_surface2: surfaces of order 2 or 4, table image in LDS, TWO ADJACENT points per lane
+// and a DEPTH-deep register prefetch of the parameter stream.
+//
+// Why (ablations on MI355X, profiles/): with one 8-byte load in flight per lane a CU keeps
+// only 16 KB of parameter loads outstanding; at ~2 us loaded HBM latency that caps the chip at
+// ~2 TB/s - removing the whole coefficient contraction from eval_stream changed its time by
+// 20 %, removing the loads' latency exposure is what matters.  Here every lane loads and stores
+// 16 bytes per instruction (points 2i, 2i+1: the coalescing sweet spot) and runs DEPTH
+// iterations ahead, i.e. DEPTH x 32 KB of loads in flight per CU.
+// Per point the arithmetic is eval_stream's (rank rotation included): bitwise identical results.
+// Requires 16-byte aligned parameter / result rows (checked by the launcher).
+// -------------------------------------------------------------------------------------
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { typedef double2 type; };
+template <> struct Vec2<float> { typedef float2 type; };
+
+constexpr int SURF2_BLOCK = 512;   // 8 waves per CU (2 per SIMD): two points per lane need > 128 VGPRs
+
+template <typename T, int O, bool DERIV, int DEPTH>
+__global__ __launch_bounds__(SURF2_BLOCK) void eval_surface2(const Desc<T> d, const TileDesc<T> td,
+                                                              const T *__restrict__ gtab,
+                                                              const unsigned *__restrict__ glut,
+                                                              const T *__restrict__ gcoef, const Params<T> prm,
+                                                              const long long N, T *__restrict__ out,
+                                                              const long long ostride, const Wrt wrt,
+                                                              unsigned long long *bad)
+{
+    static_assert(O == 2 || O == 4, "rank rotation covers orders 2 and 4");
+    typedef typename Vec2<T>::type V2;
+    constexpr int P = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tab_a = (unsigned)(size_t)smem;
+    const unsigned lut_a = tab_a + td.tab_bytes;
+    const unsigned coef_a = lut_a + td.lut_bytes;
+    {
+        T *stab = reinterpret_cast<T *>(smem);
+        unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
+        T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
+        for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+        for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
+        for (int i = threadIdx.x; i < d.coef_len; i += blockDim.x) scoef[i] = gcoef[i];
+    }
+    __syncthreads();
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes + td.coef_bytes) + (threadIdx.x & ~63);
+    const int lane = threadIdx.x & 63;
+
+    const int steps = td.lut_steps[0] > td.lut_steps[1] ? td.lut_steps[0] : td.lut_steps[1];
+    const unsigned dstride = (unsigned)d.cstride[0] * (unsigned)sizeof(T);
+    const unsigned rstride = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
+    const long long npairs = (N + 1) / 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long pn = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // pair index: points 2 pn, 2 pn + 1
+
+    // the four "variables" of the lock-step search: (point 0: u, v), (point 1: u, v)
+    Desc<T> d4 = d;
+    TileDesc<T> td4 = td;
+#pragma unroll
+    for (int k = 2; k < 4; ++k) {
+        d4.off[k] = d.off[k - 2]; d4.ncoef[k] = d.ncoef[k - 2]; d4.lo[k] = d.lo[k - 2];
+        td4.lut_scale[k] = td.lut_scale[k - 2]; td4.lut_m[k] = td.lut_m[k - 2]; td4.lut_off[k] = td.lut_off[k - 2];
+    }
+
+    const T lo0 = d.lo[0], lo1 = d.lo[1];      // register copies: see eval_stream (no flat loads)
+    auto fetch = [&](long long q, V2 (&dst)[2]) {
+        dst[0].x = lo0; dst[0].y = lo0; dst[1].x = lo1; dst[1].y = lo1;
+        if (2 * q + 1 < N) {
+            dst[0] = *reinterpret_cast<const V2 *>(prm.p[0] + 2 * q);
+            dst[1] = *reinterpret_cast<const V2 *>(prm.p[1] + 2 * q);
+        } else if (2 * q < N) {
+            dst[0].x = prm.p[0][2 * q];
+            dst[1].x = prm.p[1][2 * q];
+        }
+    };
+    V2 ring[DEPTH][2];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(pn + k * stride, ring[k]);
+
+    for (; pn < npairs; pn += stride) {
+        T u[2 * P];
+        u[0] = ring[0][0].x; u[1] = ring[0][1].x;      // point 0: (u, v)
+        u[2] = ring[0][0].y; u[3] = ring[0][1].y;      // point 1: (u, v)
+#pragma unroll
+        for (int k = 0; k + 1 < DEPTH; ++k) { ring[k][0] = ring[k + 1][0]; ring[k][1] = ring[k + 1][1]; }
+        fetch(pn + DEPTH * stride, ring[DEPTH - 1]);
+
+        bool valid[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            valid[p] = 2 * pn + p < N;
+            const bool outside = (u[2 * p] < d.lo[0]) | (u[2 * p] > d.hi[0]) | (u[2 * p + 1] < d.lo[1]) | (u[2 * p + 1] > d.hi[1]);
+            if (valid[p] && outside) record_bad(bad, 2 * pn + p);
+        }
+
+        int ix[2 * P];
+        find_spans<T, 2 * P>(tab_a, lut_a, d4, td4, steps, u, ix);
+
+        T b[P][2][O];
+        int rho[P];
+        const char *cw[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int ixp[2] = {ix[2 * p], ix[2 * p + 1]};
+            const T up[2] = {u[2 * p], u[2 * p + 1]};
+            bases_all<T, 2, O, DERIV>(tab_a, d, ixp, up, wrt, b[p]);
+            const int base = (ixp[0] - O) * d.cstride[1] + (ixp[1] - O);
+            cw[p] = smem + (coef_a - tab_a) + (unsigned)base * (unsigned)sizeof(T);
+            s_rc[lane] = 0u;
+            rho[p] = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+        }
+        T br[P][O];
+        unsigned co[P][O];
+#pragma unroll
+        for (int p = 0; p < P; ++p) rotate_basis<T, O>(b[p][1], rho[p], br[p], co[p]);
+
+        auto one_dep = [&](int dep) {
+            T res[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                T acc = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+#pragma clang fp contract(off)
+                    const char *row = cw[p] + (unsigned)a * rstride;
+                    T t;
+                    if constexpr (O == 2) {
+                        const T p0 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][0]), br[p][0]);
+                        const T p1 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][1]), br[p][1]);
+                        t = add_rn<T>(p0, p1);
+                    } else {
+                        const T p0 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][0]), br[p][0]);
+                        const T p1 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][1]), br[p][1]);
+                        const T p2 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][2]), br[p][2]);
+                        const T p3 = mul_rn<T>(*reinterpret_cast<const T *>(row + co[p][3]), br[p][3]);
+                        t = add_rn<T>(add_rn<T>(p0, p2), add_rn<T>(p1, p3));
+                    }
+                    acc = add_rn<T>(acc, mul_rn<T>(t, b[p][0][a]));
+                }
+                res[p] = acc;
+                cw[p] += dstride;
+            }
+            T *o = out + dep * ostride + 2 * pn;
+            if (valid[1]) { V2 v; v.x = res[0]; v.y = res[1]; *reinterpret_cast<V2 *>(o) = v; }
+            else if (valid[0]) o[0] = res[0];
+        };
+        if (d.nDep == 3) {
+            one_dep(0); one_dep(1); one_dep(2);
+        } else {
+            for (int dep = 0; dep < d.nDep; ++dep) one_dep(dep);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// probe_stream: memory-side floor of the evaluation kernels' launch geometry (one persistent
+// workgroup per CU with `lds` bytes of LDS allocated): streams two parameter arrays in and
+// three result arrays out, trivial arithmetic.  MODE 0: 8 bytes per lane per access (one
+// point per lane), MODE 1: 16 bytes per lane (two adjacent points).  Diagnostic only
+// (bsk_debug_probe); not part of the evaluation path.
+// -------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(TILE) void probe_stream(const double *__restrict__ u, const double *__restrict__ v,
+                                                     const long long N, double *__restrict__ out, const long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (threadIdx.x == 0) smem[0] = 1;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if constexpr (MODE == 0) {
+        for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+            const double a = u[n], b = v[n];
+            out[n] = a + b;
+            out[ostride + n] = a - b;
+            out[2 * ostride + n] = a * b;
+        }
+    } else {
+        const long long np = N / 2;
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < np; q += stride) {
+            const double2 a = *reinterpret_cast<const double2 *>(u + 2 * q), b = *reinterpret_cast<const double2 *>(v + 2 * q);
+            double2 r0, r1, r2;
+            r0.x = a.x + b.x; r0.y = a.y + b.y;
+            r1.x = a.x - b.x; r1.y = a.y - b.y;
+            r2.x = a.x * b.x; r2.y = a.y * b.y;
+            *reinterpret_cast<double2 *>(out + 2 * q) = r0;
+            *reinterpret_cast<double2 *>(out + ostride + 2 * q) = r1;
+            *reinterpret_cast<double2 *>(out + 2 * ostride + 2 * q) = r2;
         }
     }
 }

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(TILE) void eval_tile(const Desc<T> d, const TileDes
         bool outside = false;
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) {
-            u[iv] = valid ? prm.p[iv][n] : d.lo[iv];
+            u[iv] = d.lo[iv];
+            if (valid) u[iv] = prm.p[iv][n];
             outside |= (u[iv] < d.lo[iv]) | (u[iv] > d.hi[iv]);
             ix[iv] = find_span_lut<T>(tab_a + (unsigned)d.off[iv] * (unsigned)sizeof(T),
                                       lut_a + 4u * (unsigned)td.lut_off[iv], td.lut_m[iv], td.lut_steps[iv], d.lo[iv],
