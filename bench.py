@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--spinup", type=int, default=300, help="untimed launches before warm-up (clock ramp)")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +125,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock spin-up (untimed, before the W warm-up steps): an idle MI355X needs tens of
+    # milliseconds of load before its shader clock settles; the first ~100 launches of a fresh
+    # process run ~20 % slower than the steady state (tools/launch_gaps.py).
+    for _ in range(args.spinup):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()

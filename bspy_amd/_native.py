@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbspy_amd.so")
+# BSPY_AMD_LIB: alternative build of the same library (e.g. the -DBSK_ABLATE timing build)
+LIB_PATH = os.environ.get("BSPY_AMD_LIB") or os.path.join(_HERE, "csrc", "libbspy_amd.so")
 
 BSK_F32, BSK_F64 = 0, 1
 BSK_HOST, BSK_DEVICE = 0, 1
