@@ -57,6 +57,23 @@ def cpu_baseline(order, ncoef, knots, coefs, sample):
     }
 
 
+def pmc_traffic(op, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/pmc_per_launch.json: FETCH_SIZE and WRITE_SIZE in KB, collected in
+    separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide
+    coalesced reads).  None when no matching profile is committed."""
+    if op != "evaluate" or n != N_POINTS:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_final_eval_stream", "pmc_per_launch.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        k = next(v for name, v in prof.items() if "eval_stream" in name)
+        return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+    except (OSError, StopIteration, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,9 +203,11 @@ def main():
                                    f"Spline.{args.op} on {n} uniform-random (u,v) per GPU",
                        "points_per_gpu": n, "op": args.op, "sharding": "point batch sharded per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "eval_fixed<double,2,4,LDS>" if args.op != "jacobian" else "jac_fixed<double,2,4,LDS>",
-                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_eval": bpe},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.op, n),
+                         "kernel": "eval_stream<double,2,4>" if args.op != "jacobian" else "jac_fixed<double,2,4,LDS>",
+                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_eval": bpe,
+                         "algorithmic_bytes_per_launch": bpe * n,
+                         "measured_stream_floor_GBs": 5960.0},
         }
         if gathered is not None:
             res["with_allgather"] = gathered
