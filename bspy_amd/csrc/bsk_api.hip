@@ -594,6 +594,21 @@ static bool has_fixed_path(bsk_spline s)
         default: break;                                     \
     }
 
+template <typename T, int NIND, int O>
+static bsk_status launch_jac_stream(bsk_spline s, size_t lds, const Params<T> &prm, long long n, T *out, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const TileDesc<T> &td = tile_of<T>(s);
+    const long long ntiles = (n + STREAM_BLOCK - 1) / STREAM_BLOCK;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
+    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
+    HIPCHK(allow_lds(jac_stream<T, NIND, O>, lds));
+    hipLaunchKernelGGL((jac_stream<T, NIND, O>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, static_cast<const T *>(s->tab),
+                       s->lut, static_cast<const T *>(s->coef), prm, n, out, s->bad);
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
 // The asm-LDS kernels (tile / stream) cover orders 1..5: at order 6 their register windows
 // (36-value slabs, 20 table values per variable) no longer fit without spilling, which those
 // kernels must never do (check_spills.py); order 6 runs on eval_fixed.
@@ -652,6 +667,24 @@ template <typename T>
 static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
+        const size_t lds = tile_lds_bytes<T>(s, false);
+        if (lds != 0) {
+#define CALL_JACS(NIND, O) launch_jac_stream<T, NIND, O>(s, lds, prm, n, out, st)
+            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_JACS) }
+            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_JACS) }
+            else {
+                switch (s->order[0]) {      // three variables, order 5: two 25-value windows spill -> jac_fixed
+                    case 1: return CALL_JACS(3, 1);
+                    case 2: return CALL_JACS(3, 2);
+                    case 3: return CALL_JACS(3, 3);
+                    case 4: return CALL_JACS(3, 4);
+                    default: break;
+                }
+            }
+#undef CALL_JACS
+        }
+    }
     if (has_fixed_path(s)) {
         const Plan p = make_plan<T>(s, n);
 #define CALL_JAC(NIND, O) launch_jac_fixed<T, NIND, O>(s, p, prm, n, out, st)

@@ -897,6 +897,190 @@ __global__ __launch_bounds__(SURF2_BLOCK) void eval_surface2(const Desc<T> d, co
 }
 
 // -------------------------------------------------------------------------------------
+// jac_stream: fused jacobian on the LDS table image (the eval_stream of bsk_jacobian).
+// One span search and one recursion per variable give the value basis b and the
+// first-derivative basis db (they share every level but the last; the reference repeats the
+// whole evaluation nInd times, bspy/_spline_evaluation.py:205-213); each coefficient window
+// is read once and contracted against both.  out[(dep * NIND + j) * N + n]
+// -------------------------------------------------------------------------------------
+// Value levels D .. LAST-1 of one variable (counted waits as basis_levels_c).
+template <typename T, int O, int AFTER, int D, int LAST>
+__device__ __forceinline__ void basis_levels_upto(T u, const T (&kn)[O], T (&rc)[O][O], T (&b)[O])
+{
+    if constexpr (D < LAST) {
+        constexpr int younger = (O * (O - 1) - D * (D + 1)) / 2 + AFTER;
+        lds_wait_c<younger, D>(rc[D]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int bi = O - D + j;
+            const T alpha = (u - kn[(O - 1) - D + j]) * rc[D][j];
+            b[bi - 1] += (T(1) - alpha) * b[bi];
+            b[bi] *= alpha;
+        }
+        basis_levels_upto<T, O, AFTER, D + 1, LAST>(u, kn, rc, b);
+    }
+}
+
+template <typename T, int NIND, int O, int IV>
+__device__ __forceinline__ void bases_d1_compute(const T (&u)[NIND], T (&kn)[NIND][O], T (&rc)[NIND][O][O],
+                                                 T (&b)[NIND][O], T (&db)[NIND][O])
+{
+    if constexpr (IV < NIND) {
+        constexpr int per_axis = (O - 1) + (O * (O - 1)) / 2;
+        constexpr int after = (NIND - 1 - IV) * per_axis;
+#pragma unroll
+        for (int k = 0; k < O; ++k) { b[IV][k] = T(0); db[IV][k] = T(0); }
+        b[IV][O - 1] = T(1);
+        if constexpr (O > 1) {
+            lds_wait_c<(O * (O - 1)) / 2 + after, O - 1>(kn[IV]);
+            // levels 1 .. O-2 are shared by b and db; the last level is run twice
+            T lvl[O];
+#pragma unroll
+            for (int k = 0; k < O; ++k) lvl[k] = b[IV][k];
+            basis_levels_upto<T, O, after, 1, O - 1>(u[IV], kn[IV], rc[IV], lvl);      // order O-1 basis
+#pragma unroll
+            for (int k = 0; k < O; ++k) { b[IV][k] = lvl[k]; db[IV][k] = lvl[k]; }
+            constexpr int D = O - 1;
+            lds_wait_c<after, D>(rc[IV][D]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int bi = O - D + j;
+                const T r = rc[IV][D][j];
+                const T alpha = (u[IV] - kn[IV][(O - 1) - D + j]) * r;
+                const T dalpha = T(D) * r;
+                b[IV][bi - 1] += (T(1) - alpha) * b[IV][bi];
+                b[IV][bi] *= alpha;
+                db[IV][bi - 1] -= dalpha * db[IV][bi];
+                db[IV][bi] *= dalpha;
+            }
+        }
+        bases_d1_compute<T, NIND, O, IV + 1>(u, kn, rc, b, db);
+    }
+}
+
+template <typename T, int NIND, int O>
+__global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, const TileDesc<T> td,
+                                                           const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                           const T *__restrict__ gcoef, const Params<T> prm,
+                                                           const long long N, T *__restrict__ out,
+                                                           unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tab_a = (unsigned)(size_t)smem;
+    const unsigned lut_a = tab_a + td.tab_bytes;
+    const unsigned coef_a = lut_a + td.lut_bytes;
+    {
+        T *stab = reinterpret_cast<T *>(smem);
+        unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
+        T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
+        for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+        for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
+        for (int i = threadIdx.x; i < d.coef_len; i += blockDim.x) scoef[i] = gcoef[i];
+    }
+    __syncthreads();
+    int steps = 0;
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) steps = td.lut_steps[iv] > steps ? td.lut_steps[iv] : steps;
+    const unsigned dstride = (unsigned)d.cstride[0] * (unsigned)sizeof(T);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    T lo_r[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) lo_r[iv] = d.lo[iv];
+    T un[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) { un[iv] = lo_r[iv]; if (n < N) un[iv] = prm.p[iv][n]; }
+
+    for (; n < N; n += stride) {
+        T u[NIND];
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            u[iv] = un[iv];
+            outside |= (u[iv] < lo_r[iv]) | (u[iv] > d.hi[iv]);
+            un[iv] = lo_r[iv];
+        }
+        if (n + stride < N) {
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) un[iv] = prm.p[iv][n + stride];
+        }
+        if (outside) record_bad(bad, n);
+
+        int ix[NIND];
+        find_spans<T, NIND>(tab_a, lut_a, d, td, steps, u, ix);
+        T b[NIND][O], db[NIND][O];
+        {
+            T kn[NIND][O];
+            T rc[NIND][O][O];
+            if constexpr (O > 1) {
+#pragma unroll
+                for (int iv = 0; iv < NIND; ++iv) {
+                    const unsigned ta = tab_a + (unsigned)d.off[iv] * (unsigned)sizeof(T);
+                    lds_issue_n<T, O - 1, O>(ta + (unsigned)(ix[iv] - (O - 1)) * (unsigned)sizeof(T), kn[iv]);
+                    basis_issue<T, O, 1>(ta, d.nk[iv], ix[iv], rc[iv]);
+                }
+            }
+            bases_d1_compute<T, NIND, O, 0>(u, kn, rc, b, db);
+        }
+        unsigned caddr = coef_a;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)((ix[iv] - O) * d.cstride[iv + 1]) * (unsigned)sizeof(T);
+
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            T *o = out + (long long)dep * NIND * N + n;
+            if constexpr (NIND == 1) {
+                T c[1][O];
+                block_issue<T, 1, O>(caddr, 0u, c);
+                block_wait<0>(c);
+                o[0] = row_fma<T, O>(c, db[0]);
+            } else if constexpr (NIND == 2) {
+                T c[O][O];
+                block_issue<T, O, O>(caddr, (unsigned)d.cstride[1] * (unsigned)sizeof(T), c);
+                block_wait<0>(c);
+                T j0 = T(0), j1 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T t = T(0), tdv = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) { t += c[a][k] * b[1][k]; tdv += c[a][k] * db[1][k]; }
+                    j0 += t * db[0][a];
+                    j1 += tdv * b[0][a];
+                }
+                o[0] = j0;
+                o[N] = j1;
+            } else {
+                const unsigned s0 = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
+                const unsigned s1 = (unsigned)d.cstride[2] * (unsigned)sizeof(T);
+                T j0 = T(0), j1 = T(0), j2 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T c[O][O];
+                    block_issue<T, O, O>(caddr + (unsigned)a * s0, s1, c);
+                    block_wait<0>(c);
+                    T sv = T(0), sb = T(0), sc = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        T t = T(0), tdv = T(0);
+#pragma unroll
+                        for (int m = 0; m < O; ++m) { t += c[k][m] * b[2][m]; tdv += c[k][m] * db[2][m]; }
+                        sv += t * b[1][k];
+                        sb += t * db[1][k];
+                        sc += tdv * b[1][k];
+                    }
+                    j0 += sv * db[0][a];
+                    j1 += sb * b[0][a];
+                    j2 += sc * b[0][a];
+                }
+                o[0] = j0;
+                o[N] = j1;
+                o[2 * N] = j2;
+            }
+            caddr += dstride;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // probe_stream: memory-side floor of the evaluation kernels' launch geometry (one persistent
 // workgroup per CU with `lds` bytes of LDS allocated): streams two parameter arrays in and
 // three result arrays out, trivial arithmetic.  MODE 0: 8 bytes per lane per access (one
