@@ -12,6 +12,7 @@
 #include "bsk_tile.hpp"
 #include "bsk_stream.hpp"
 #include "bsk_surface.hpp"
+#include "bsk_rowrot.hpp"
 
 using namespace bsk;
 
@@ -499,6 +500,28 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     bool deriv = false;
     for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
+    if constexpr (NIND == 2 && (O == 2 || O == 4)) {
+        // default surface kernel: row rotation on an odd-stride LDS image
+        const TileDesc<T> &tdr = tile_of<T>(s);
+        const size_t rs = (size_t)(s->ncoef[1] | 1);
+        const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
+        const size_t lds_rr = (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
+        if ((s->variant == 0 || s->variant == 9) && lds_rr <= s->lds_max) {
+            const long long nt = (n + TILE - 1) / TILE;
+            const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
+            if (deriv) {
+                HIPCHK(allow_lds(eval_rowrot<T, O, true>, lds_rr));
+                hipLaunchKernelGGL((eval_rowrot<T, O, true>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, prm, n,
+                                   out, ostride, w, s->bad);
+            } else {
+                HIPCHK(allow_lds(eval_rowrot<T, O, false>, lds_rr));
+                hipLaunchKernelGGL((eval_rowrot<T, O, false>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, prm, n,
+                                   out, ostride, w, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
     if constexpr (NIND == 2) {
         // plain-C++ surface kernel, one (variant 7) or two (variant 8) points per lane
         const bool aligned2 = (((uintptr_t)prm.p[0] | (uintptr_t)prm.p[1] | (uintptr_t)out) & 15) == 0 &&

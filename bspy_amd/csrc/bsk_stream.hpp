@@ -126,12 +126,19 @@ __device__ __forceinline__ void basis_levels_c(T u, int wrt, const T (&kn)[O], T
         constexpr int younger = (O * (O - 1) - D * (D + 1)) / 2 + AFTER;
         lds_wait_c<younger, D>(rc[D]);
         if (!DERIV || D < O - wrt) {
+            if constexpr (D == 1) {
+                // first level on b = (0, .., 0, 1): written out, hipcc may not fold 0 + x * 1
+                const T alpha = (u - kn[O - 2]) * rc[1][0];
+                b[O - 2] = T(1) - alpha;
+                b[O - 1] = alpha;
+            } else {
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const int bi = O - D + j;
-                const T alpha = (u - kn[(O - 1) - D + j]) * rc[D][j];
-                b[bi - 1] += (T(1) - alpha) * b[bi];
-                b[bi] *= alpha;
+                for (int j = 0; j < D; ++j) {
+                    const int bi = O - D + j;
+                    const T alpha = (u - kn[(O - 1) - D + j]) * rc[D][j];
+                    b[bi - 1] += (T(1) - alpha) * b[bi];
+                    b[bi] *= alpha;
+                }
             }
         } else {
 #pragma unroll
@@ -208,6 +215,30 @@ __device__ __forceinline__ T add_rn(T a, T b)
 {
 #pragma clang fp contract(off)
     return a + b;
+}
+
+// br[j] = b[(j + rho) mod O] (values only; see rotate_basis for the select staging)
+template <typename T, int O>
+__device__ __forceinline__ void rotate_basis_values(const T (&b)[O], int rho, T (&br)[O])
+{
+    static_assert(O == 2 || O == 4, "rank rotation covers orders 2 and 4");
+    int r0i = rho & 1, r1i = rho & 2;
+    asm volatile("" : "+v"(r0i), "+v"(r1i));
+    const bool r0 = r0i != 0, r1 = r1i != 0;
+    if constexpr (O == 2) {
+        T v0 = b[0], v1 = b[1];
+        asm volatile("" : "+v"(v0), "+v"(v1));
+        br[0] = r0 ? v1 : v0;
+        br[1] = r0 ? v0 : v1;
+    } else {
+        T v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        const T t0 = r0 ? v1 : v0, t1 = r0 ? v2 : v1, t2 = r0 ? v3 : v2, t3 = r0 ? v0 : v3;
+        br[0] = r1 ? t2 : t0;
+        br[1] = r1 ? t3 : t1;
+        br[2] = r1 ? t0 : t2;
+        br[3] = r1 ? t1 : t3;
+    }
 }
 
 template <typename T, int O>

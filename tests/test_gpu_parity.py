@@ -322,7 +322,7 @@ def test_empty_and_ragged():
         assert np.abs(out - orc).max() <= 1e-12 * _scale(orc)
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "4", "5", "6", "7", "8"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4", "5", "6", "7", "8", "9"])
 def test_kernel_variants(variant, golden_parity, monkeypatch):
     """BSK_VARIANT pins the kernel family (1 simple, 2 LDS tile, 3 LDS tile + bank-class
     permutation); every family must meet the same parity bar on its own."""
