@@ -64,11 +64,11 @@ def pmc_traffic(op, n):
     coalesced reads).  None when no matching profile is committed."""
     if op != "evaluate" or n != N_POINTS:
         return None
-    path = os.path.join(ROOT, "profiles", "r01_final_eval_stream", "pmc_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_eval_rowrot", "pmc_per_launch.json")
     try:
         with open(path) as f:
             prof = json.load(f)
-        k = next(v for name, v in prof.items() if "eval_stream" in name)
+        k = next(v for name, v in prof.items() if "eval_rowrot" in name)
         return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
     except (OSError, StopIteration, KeyError, ValueError):
         return None
@@ -210,7 +210,7 @@ def main():
                        "points_per_gpu": n, "op": args.op, "sharding": "point batch sharded per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.op, n),
-                         "kernel": "eval_stream<double,2,4>" if args.op != "jacobian" else "jac_fixed<double,2,4,LDS>",
+                         "kernel": "eval_rowrot<double,4>" if args.op != "jacobian" else "jac_stream<double,2,4>",
                          "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_eval": bpe,
                          "algorithmic_bytes_per_launch": bpe * n,
                          "measured_stream_floor_GBs": 5960.0},

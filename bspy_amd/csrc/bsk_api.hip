@@ -13,6 +13,7 @@
 #include "bsk_stream.hpp"
 #include "bsk_surface.hpp"
 #include "bsk_rowrot.hpp"
+#include "bsk_gather.hpp"
 
 using namespace bsk;
 
@@ -71,6 +72,7 @@ struct bsk_spline_s {
     TileDesc<double> t64;
     void *tab = nullptr;     // device axis table
     void *coef = nullptr;    // device coefficients
+    void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
     unsigned *lut = nullptr; // device span-search bucket tables
     int dbg = 0;             // BSK_DEBUG: timing-only ablation bits of eval_perm (results wrong)
     int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream, 5 perm (pipelined bank permutation), 6 surface2 (two points per lane)
@@ -176,6 +178,15 @@ static bsk_status upload_tables(bsk_spline s, const void *const *knots, const vo
     if (d.tab_len) HIPCHK(hipMemcpy(s->tab, tab.data(), sizeof(T) * tab.size(), hipMemcpyHostToDevice));
     if (td.lut_len) HIPCHK(hipMemcpy(s->lut, lut.data(), sizeof(unsigned) * lut.size(), hipMemcpyHostToDevice));
     if (d.coef_len) HIPCHK(hipMemcpy(s->coef, coefs, sizeof(T) * (size_t)d.coef_len, hipMemcpyHostToDevice));
+    if (s->coef_aos) {
+        // (nDep, cells) -> (cells, nDep)
+        const size_t cells = (size_t)d.coef_len / (size_t)s->nDep;
+        std::vector<T> aos((size_t)d.coef_len);
+        const T *src = static_cast<const T *>(coefs);
+        for (int dep = 0; dep < s->nDep; ++dep)
+            for (size_t c = 0; c < cells; ++c) aos[c * s->nDep + dep] = src[(size_t)dep * cells + c];
+        HIPCHK(hipMemcpy(s->coef_aos, aos.data(), sizeof(T) * aos.size(), hipMemcpyHostToDevice));
+    }
     return BSK_OK;
 }
 
@@ -275,6 +286,7 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
         if (s->coef) (void)hipFree(s->coef);
         if (s->bad) (void)hipFree(s->bad);
         if (s->lut) (void)hipFree(s->lut);
+        if (s->coef_aos) (void)hipFree(s->coef_aos);
         delete s;
     };
 #define HIPCHK_C(expr)                                                                        \
@@ -294,6 +306,12 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
                                                   : (size_t)64 * 1024);
     HIPCHK_C(hipMalloc(&s->tab, std::max<size_t>(16, s->esize * (size_t)tab_len)));
     HIPCHK_C(hipMalloc(&s->coef, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+    {
+        const size_t tbytes = s->esize * (size_t)tab_len + s->esize * (size_t)coef_len;
+        bool fixed = s->same_order && nInd <= 3 && order[0] <= 6;
+        if (fixed && nDep <= 4 && tbytes + 8192 > s->lds_max)
+            HIPCHK_C(hipMalloc(&s->coef_aos, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+    }
     HIPCHK_C(hipMalloc((void **)&s->lut, std::max<size_t>(16, sizeof(unsigned) * (size_t)(dtype == BSK_F32 ? s->t32.lut_len : s->t64.lut_len))));
     HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
     if (const char *v = getenv("BSK_VARIANT")) s->variant = atoi(v);
@@ -323,6 +341,7 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     if (s->coef) (void)hipFree(s->coef);
     if (s->bad) (void)hipFree(s->bad);
     if (s->lut) (void)hipFree(s->lut);
+    if (s->coef_aos) (void)hipFree(s->coef_aos);
     s->in_ws.release();
     s->out_ws.release();
     s->aux_ws.release();
@@ -600,6 +619,33 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
     return BSK_OK;
 }
 
+template <typename T, int NIND, int O>
+static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                     const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const size_t lds = sizeof(T) * (size_t)d.tab_len;
+    if (lds > s->lds_max / 2) return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
+    const int block = 256;
+    const long long blocks = (n + block - 1) / block;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *aos = static_cast<const T *>(s->coef_aos);
+#define GATHER_ND(ND)                                                                                             \
+    case ND:                                                                                                      \
+        HIPCHK(allow_lds(eval_gather<T, NIND, O, ND>, lds));                                                      \
+        hipLaunchKernelGGL((eval_gather<T, NIND, O, ND>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, n, out, \
+                           ostride, w, s->bad);                                                                   \
+        break;
+    switch (s->nDep) {
+        GATHER_ND(1) GATHER_ND(2) GATHER_ND(3) GATHER_ND(4)
+        default: return fail(BSK_ERR_INVALID, "internal: eval_gather needs nDep <= 4");
+    }
+#undef GATHER_ND
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
 // Fast-path coverage: nInd 1..3, one common order 1..6.
 static bool has_fixed_path(bsk_spline s)
 {
@@ -674,6 +720,13 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
             else { BSK_ORDER_SWITCH5(3, CALL_TILE) }
 #undef CALL_TILE
         }
+    }
+    if (has_fixed_path(s) && s->coef_aos && s->variant != 1) {
+#define CALL_GATHER(NIND, O) launch_eval_gather<T, NIND, O>(s, prm, n, out, ostride, w, st)
+        if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_GATHER) }
+        else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_GATHER) }
+        else { BSK_ORDER_SWITCH(3, CALL_GATHER) }
+#undef CALL_GATHER
     }
     if (has_fixed_path(s)) {
         const Plan p = make_plan<T>(s, n);

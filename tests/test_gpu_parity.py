@@ -351,3 +351,33 @@ def test_kernel_variants(variant, golden_parity, monkeypatch):
     with pytest.raises(bspy_amd.DomainError) as e:
         t.evaluate(bad)
     assert e.value.index == 5000
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 3, (4,), (50_000,), np.float64),          # 1.2 MB curve table
+    (2, 2, (4, 4), (200, 150), np.float64),       # 480 KB surface table
+    (2, 4, (3, 3), (300, 300), np.float32),       # 1.4 MB, nDep 4 (one 16-byte load per control point)
+    (3, 1, (3, 3, 3), (50, 40, 30), np.float64),  # 480 KB volume, nDep 1
+    (3, 4, (5, 5, 5), (40, 40, 40), np.float32),  # cfg5 shape
+])
+def test_large_tables_gathered_from_l2(shape):
+    """Tables that do not fit in LDS run on the control-point-major gather kernel."""
+    nind, ndep, order, ncoef, dt = shape
+    rng = np.random.default_rng(42)
+    knots = [cases.nonuniform_knots(rng, o, c, dt, -1.0, 2.0) for o, c in zip(order, ncoef)]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+    n = 20_000
+    pts = [(-1.0 + 3.0 * rng.random(n)).astype(dt) for _ in range(nind)]
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    tol = 2e-5 if dt == np.float32 else 1e-12
+    for w in ([0] * nind, [1] + [0] * (nind - 1), [0] * (nind - 1) + [2]):
+        out = t.evaluate(pts, w)
+        orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, pts)
+        assert bad == -1
+        assert np.abs(out - orc).max() <= tol * _scale(orc), (shape, w)
+    # update() must refresh the control-point-major copy too
+    coefs2 = coefs * 0.5
+    t.update(knots, coefs2)
+    out = t.evaluate(pts)
+    orc, _ = oracle.c_evaluate(order, ncoef, knots, coefs2, [0] * nind, pts)
+    assert np.abs(out - orc).max() <= tol * _scale(orc)
