@@ -743,6 +743,28 @@ template <typename T>
 static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
+    if (has_fixed_path(s) && s->nInd == 2 && (s->order[0] == 2 || s->order[0] == 4) && (s->variant == 0 || s->variant == 9)) {
+        const TileDesc<T> &tdr = tile_of<T>(s);
+        const size_t rs = (size_t)(s->ncoef[1] | 1);
+        const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
+        const size_t lds_rr = (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
+        if (lds_rr <= s->lds_max) {
+            const Desc<T> &d = desc_of<T>(s);
+            const long long nt = (n + TILE - 1) / TILE;
+            const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
+            const T *tab = static_cast<const T *>(s->tab);
+            const T *coef = static_cast<const T *>(s->coef);
+            if (s->order[0] == 4) {
+                HIPCHK(allow_lds(jac_rowrot<T, 4>, lds_rr));
+                hipLaunchKernelGGL((jac_rowrot<T, 4>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out, s->bad);
+            } else {
+                HIPCHK(allow_lds(jac_rowrot<T, 2>, lds_rr));
+                hipLaunchKernelGGL((jac_rowrot<T, 2>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         const size_t lds = tile_lds_bytes<T>(s, false);
         if (lds != 0) {

@@ -111,4 +111,106 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     }
 }
 
+// jac_rowrot: the fused jacobian (see jac_stream) on the odd-stride image with row rotation.
+// Per dependent variable the window is read once; every row gives t_a = sum_k c[a][k] b1[k] and
+// td_a = sum_k c[a][k] db1[k]; du = sum_a t_a db0[a] and dv = sum_a td_a b0[a] are combined with
+// the rotation-invariant tree.  out[(dep * 2 + j) * N + n]
+template <typename T, int O>
+__global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDesc<T> td,
+                                                   const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                   const T *__restrict__ gcoef, const Params<T> prm,
+                                                   const long long N, T *__restrict__ out, unsigned long long *bad)
+{
+    static_assert(O == 2 || O == 4, "row rotation covers orders 2 and 4");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tab_a = (unsigned)(size_t)smem;
+    const unsigned lut_a = tab_a + td.tab_bytes;
+    const unsigned coef_a = lut_a + td.lut_bytes;
+    const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
+    const int rs = nc1 | 1;
+    const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
+    {
+        T *stab = reinterpret_cast<T *>(smem);
+        unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
+        T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
+        for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+        for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
+        for (int i = threadIdx.x; i < d.coef_len; i += blockDim.x) {
+            const int row = i / nc1, col = i - row * nc1;
+            scoef[row * rs + col] = gcoef[i];
+        }
+    }
+    __syncthreads();
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes +
+                                                 (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
+    const int lane = threadIdx.x & 63;
+    const int steps = td.lut_steps[0] > td.lut_steps[1] ? td.lut_steps[0] : td.lut_steps[1];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long n = ((long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64 + lane;
+    const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
+    T un[2] = {lo0, lo1};
+    if (n < N) { un[0] = prm.p[0][n]; un[1] = prm.p[1][n]; }
+
+    for (; n < N; n += stride) {
+        const T u[2] = {un[0], un[1]};
+        const bool outside = (u[0] < lo0) | (u[0] > hi0) | (u[1] < lo1) | (u[1] > hi1);
+        un[0] = lo0; un[1] = lo1;
+        if (n + stride < N) { un[0] = prm.p[0][n + stride]; un[1] = prm.p[1][n + stride]; }
+        if (outside) record_bad(bad, n);
+
+        int ix[2];
+        find_spans<T, 2>(tab_a, lut_a, d, td, steps, u, ix);
+        T b[2][O], db[2][O];
+        {
+            T kn[2][O];
+            T rc[2][O][O];
+            if constexpr (O > 1) {
+#pragma unroll
+                for (int iv = 0; iv < 2; ++iv) {
+                    const unsigned ta = tab_a + (unsigned)d.off[iv] * (unsigned)sizeof(T);
+                    lds_issue_n<T, O - 1, O>(ta + (unsigned)(ix[iv] - (O - 1)) * (unsigned)sizeof(T), kn[iv]);
+                    basis_issue<T, O, 1>(ta, d.nk[iv], ix[iv], rc[iv]);
+                }
+            }
+            bases_d1_compute<T, 2, O, 0>(u, kn, rc, b, db);
+        }
+        const int base = (ix[0] - O) * rs + (ix[1] - O);
+        s_rc[lane] = 0u;
+        const int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+        T b0r[O], db0r[O];
+        rotate_basis_values<T, O>(b[0], rho, b0r);
+        rotate_basis_values<T, O>(db[0], rho, db0r);
+        unsigned ra[O];
+#pragma unroll
+        for (int a = 0; a < O; ++a)
+            ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
+
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            T c[O][O];
+#pragma unroll
+            for (int a = 0; a < O; ++a) lds_issue_row<T, O>(ra[a], c[a]);
+            block_wait<0>(c);
+            T qu[O], qv[O];
+#pragma unroll
+            for (int a = 0; a < O; ++a) {
+                T t = T(0), tdv = T(0);
+#pragma unroll
+                for (int k = 0; k < O; ++k) { t += c[a][k] * b[1][k]; tdv += c[a][k] * db[1][k]; }
+                qu[a] = mul_rn<T>(t, db0r[a]);
+                qv[a] = mul_rn<T>(tdv, b0r[a]);
+            }
+            T *o = out + (long long)dep * 2 * N + n;
+            if constexpr (O == 2) {
+                o[0] = add_rn<T>(qu[0], qu[1]);
+                o[N] = add_rn<T>(qv[0], qv[1]);
+            } else {
+                o[0] = add_rn<T>(add_rn<T>(qu[0], qu[2]), add_rn<T>(qu[1], qu[3]));
+                o[N] = add_rn<T>(add_rn<T>(qv[0], qv[2]), add_rn<T>(qv[1], qv[3]));
+            }
+#pragma unroll
+            for (int a = 0; a < O; ++a) ra[a] += dstride;
+        }
+    }
+}
+
 }  // namespace bsk

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_pmc.sh <tag> [env VAR=..] -- quick PMC passes of bench.py (3 steps)
+# usage: bash tools/pmc.sh <tag> [env VAR=..] -- quick PMC passes of bench.py (3 steps)
 tag=$1; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_$tag

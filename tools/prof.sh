@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag> [bench args...]
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag> [bench args...]
 # kernel-trace stats + two separate PMC passes, summaries under gpurun_out/prof_<tag>/
 set -e
 tag=$1; shift

@@ -1,4 +1,4 @@
-"""Condense a gpurun_out/prof_<tag> (tools_prof.sh) or pmc_<tag> (tools_pmc.sh) directory into
+"""Condense a gpurun_out/prof_<tag> (tools/prof.sh) or pmc_<tag> (tools/pmc.sh) directory into
 profiles/<name>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats) and pmc_per_launch.json
 (average per launch of every collected counter, bsk:: kernels only)."""
 import collections, csv, glob, json, os, shutil, sys
