@@ -9,6 +9,7 @@ error messages for
     s.jacobian(uvw) / s.tangent_space(uvw)                        spline.py:1354-1377, :2238-2252
     s.domain()                                                    spline.py:794-808
     Spline.bspline_values(knot, knots, splineOrder, u, ...)       spline.py:207-252
+    to_dict / from_dict / load / save (JSON, as an input format)   spline.py:1099-1125, :1542-1583, :1998-2026, :2254-2267
 
 The arithmetic runs on the GPU (bspy_amd/_spline_evaluation.py -> libbspy_amd.so); the
 rest of the reference's Spline API (fitting, intersection, CSG, viewer) is out of scope.
@@ -143,6 +144,54 @@ class Spline:
     def domain(self):
         """nInd x 2 array of parameter bounds (reference spline.py:794-808)."""
         return _ev.domain(self)
+
+    # ------------------------------------------------------------------ persistence (input format)
+    def to_dict(self):
+        """`dict` with the spline's data (reference spline.py:2254-2267)."""
+        return {"type": "Spline", "nInd": self.nInd, "nDep": self.nDep, "order": self.order, "nCoef": self.nCoef,
+                "knots": self.knots, "coefs": self.coefs, "metadata": self.metadata}
+
+    @staticmethod
+    def from_dict(dictionary):
+        """Spline from a `dict` as written by `to_dict` / the reference's files, including the
+        legacy "flipNormal" metadata key (reference spline.py:1099-1125)."""
+        spline = Spline(dictionary["nInd"], dictionary["nDep"], dictionary["order"], dictionary["nCoef"],
+                        [np.array(knots) for knots in dictionary["knots"]], np.array(dictionary["coefs"]),
+                        dictionary.get("metadata", {}))
+        if spline.metadata.get("flipNormal", False):
+            spline.metadata["negateNormal"] = True
+            del spline.metadata["flipNormal"]
+        return spline
+
+    @staticmethod
+    def load(fileName):
+        """List of splines from a JSON file in the reference's format: one object or a list of
+        objects, nested `coefs` of shape (nDep, *nCoef) (reference spline.py:1542-1583; the
+        legacy .npz branch is not supported)."""
+        import json
+        with open(fileName, "r", encoding="utf-8") as file:
+            data = json.load(file)
+        if isinstance(data, dict):
+            data = [data]
+        return [Spline.from_dict(d) for d in data if d.get("type", "Spline") == "Spline"]
+
+    def save(self, fileName, *additional_splines):
+        """Write this spline (and more) as JSON in the reference's format (spline.py:1998-2026)."""
+        import json
+
+        class SplineEncoder(json.JSONEncoder):
+            def default(self, obj):
+                if isinstance(obj, np.ndarray):
+                    return obj.tolist()
+                if isinstance(obj, Spline):
+                    return obj.to_dict()
+                return super().default(obj)
+
+        with open(fileName, "w", encoding="utf-8") as file:
+            if additional_splines:
+                json.dump((self, *additional_splines), file, indent=4, cls=SplineEncoder)
+            else:
+                json.dump(self, file, indent=4, cls=SplineEncoder)
 
     # ------------------------------------------------------------------ device tables
     def device_tables(self, device=None):

@@ -213,3 +213,25 @@ def test_sharded_evaluator_gloo_world2(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out}"
         assert f"rank {r} ok" in out
+
+
+def test_json_round_trip_and_reference_files(tmp_path):
+    """The reference's JSON format as an input format: files from the reference's
+    own test suite load, and save -> load reproduces the spline."""
+    ref_dir = os.path.join(ROOT, "tests", "golden", "reference_json")
+    loaded = Spline.load(os.path.join(ref_dir, "offset-issue.json"))
+    assert len(loaded) == 5 and all(s.nInd == 1 and s.nDep == 2 and s.order == (4,) for s in loaded)
+    s = Spline.load(os.path.join(ref_dir, "reverse-thing.json"))[0]
+    assert (s.nInd, s.nDep, s.order, s.nCoef) == (1, 2, (7,), (112,)) and s.coefs.shape == (2, 112)
+    path = tmp_path / "out.json"
+    k2 = [[0, 0, 0, .5, 1, 1, 1], [0, 0, 0, 0, .5, 1, 1, 1, 1]]
+    a = Spline(2, 3, [3, 4], [4, 5], k2, np.arange(60.0).reshape(3, 4, 5), {"Name": "a", "flipNormal": True})
+    a.save(str(path), s)
+    back = Spline.load(str(path))
+    assert len(back) == 2
+    assert back[0].order == a.order and back[0].nCoef == a.nCoef
+    assert np.array_equal(back[0].coefs, a.coefs) and all(np.array_equal(x, y) for x, y in zip(back[0].knots, a.knots))
+    assert back[0].metadata == {"Name": "a", "negateNormal": True}          # legacy key translated on load
+    assert np.array_equal(back[1].coefs, s.coefs)
+    d = a.to_dict()
+    assert d["type"] == "Spline" and Spline.from_dict(d).nDep == 3
