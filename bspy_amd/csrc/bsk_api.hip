@@ -951,20 +951,22 @@ static bsk_status run_grid(bsk_spline s, const int *wrt, const void *const *grid
     int *ixs = reinterpret_cast<int *>(base + par_b + row_b);
     unsigned char *outside = reinterpret_cast<unsigned char *>(base + par_b + row_b + ix_b);
 
+    GridAxes<T> ax;
+    long long nmax = 1;
+    for (int iv = 0; iv < MAXI; ++iv) { ax.u[iv] = nullptr; ax.wrt[iv] = 0; }
     for (int iv = 0; iv < s->nInd; ++iv) {
         const T *u = static_cast<const T *>(grid[iv]);
         if (mem == BSK_HOST) {
             HIPCHK(hipMemcpyAsync(dpar + g.goff[iv], u, sizeof(T) * (size_t)ngrid[iv], hipMemcpyHostToDevice, st));
             u = dpar + g.goff[iv];
         }
-        const int block = 256;
-        const int blocks = (int)((ngrid[iv] + block - 1) / block);
-        hipLaunchKernelGGL((basis_rows<T>), dim3(blocks), dim3(block), 0, st,
-                           static_cast<const T *>(s->tab) + d.off[iv], d.nk[iv], d.order[iv], d.ncoef[iv],
-                           d.steps[iv], u, (long long)ngrid[iv], wrt ? wrt[iv] : 0, 0, (const int *)nullptr,
-                           ixs + g.goff[iv], rows + g.roff[iv], d.lo[iv], d.hi[iv], outside + g.goff[iv]);
-        HIPCHK(hipGetLastError());
+        ax.u[iv] = u;
+        ax.wrt[iv] = wrt ? wrt[iv] : 0;
+        nmax = std::max<long long>(nmax, ngrid[iv]);
     }
+    hipLaunchKernelGGL((basis_rows_grid<T>), dim3((unsigned)((nmax + 255) / 256), (unsigned)s->nInd), dim3(256), 0, st, d,
+                       static_cast<const T *>(s->tab), ax, g, ixs, rows, outside);
+    HIPCHK(hipGetLastError());
 
     T *dout = static_cast<T *>(out);
     if (mem == BSK_HOST) {
@@ -973,7 +975,25 @@ static bsk_status run_grid(bsk_spline s, const int *wrt, const void *const *grid
     }
     const T *coef = static_cast<const T *>(s->coef);
     bool launched = false;
-    if (s->nInd == 2 && s->same_order && g.n[0] <= 65535) {
+    const size_t rowc_bytes = sizeof(T) * (size_t)s->nDep * (size_t)(s->nInd == 2 ? s->ncoef[1] : 0);
+    if (s->nInd == 2 && s->same_order && s->order[0] <= 6 && rowc_bytes <= 48 * 1024 && g.n[1] >= 64 && s->variant != 1) {
+        // row-factored surface grid
+        constexpr long long VEC = 16 / (long long)sizeof(T);
+        const int vec_ok = (g.n[1] % VEC == 0) && ((reinterpret_cast<uintptr_t>(dout) & 15) == 0) ? 1 : 0;
+        const int gridx = (int)std::max<long long>(1, std::min<long long>(g.n[0], (long long)s->num_cu * 8));
+#define GRID_ROWS(O)                                                                                           \
+    case O:                                                                                                    \
+        hipLaunchKernelGGL((grid_rows<T, O>), dim3(gridx), dim3(256), rowc_bytes, st, d, coef, g, ixs, rows,   \
+                           outside, dout, s->bad, vec_ok);                                                     \
+        launched = true;                                                                                       \
+        break;
+        switch (s->order[0]) {
+            GRID_ROWS(1) GRID_ROWS(2) GRID_ROWS(3) GRID_ROWS(4) GRID_ROWS(5) GRID_ROWS(6)
+            default: break;
+        }
+#undef GRID_ROWS
+    }
+    if (!launched && s->nInd == 2 && s->same_order && g.n[0] <= 65535) {
         const int block = 256;
         const int gx = (int)std::max<long long>(1, std::min<long long>((g.n[1] + block - 1) / block, 64));
 #define GRID_SURF(O)                                                                                           \

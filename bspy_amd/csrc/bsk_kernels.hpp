@@ -229,6 +229,39 @@ __global__ __launch_bounds__(256) void basis_rows(const T *__restrict__ tab, int
     if (outside) outside[i] = (x < lo) | (x > hi);
 }
 
+struct GridDims {
+    long long n[MAXI];     // grid points per variable
+    long long goff[MAXI];  // offset of variable iv in ixs / outside; rows offset = goff * order (see roff)
+    long long roff[MAXI];  // offset of variable iv in rows
+};
+
+// Stage 1 of the tensor-product grid for ALL variables in one launch (blockIdx.y = variable):
+// span index, basis row and out-of-domain flag of every grid parameter.
+template <typename T>
+struct GridAxes {
+    const T *u[MAXI];      // grid parameters of variable iv (device)
+    int wrt[MAXI];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void basis_rows_grid(const Desc<T> d, const T *__restrict__ gtab, const GridAxes<T> ax,
+                                                       const GridDims g, int *__restrict__ ixs, T *__restrict__ rows,
+                                                       unsigned char *__restrict__ outside)
+{
+    const int iv = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n[iv]) return;
+    const T *tab = gtab + d.off[iv];
+    const int order = d.order[iv];
+    const T x = ax.u[iv][i];
+    T b[MAXO];
+    const int ix = find_span<T>(tab, order, d.ncoef[iv], d.steps[iv], x);
+    basis_runtime<T>(tab, d.nk[iv], order, ix, x, ax.wrt[iv], false, b);
+    ixs[g.goff[iv] + i] = ix;
+    for (int k = 0; k < order; ++k) rows[g.roff[iv] + i * order + k] = b[k];
+    outside[g.goff[iv] + i] = (x < d.lo[iv]) | (x > d.hi[iv]);
+}
+
 // ---------------------------------------------------------------------------------
 // tensor-product grid, stage 2: one lane per output point, last grid variable fastest
 // (coalesced stores).  Basis rows come from stage 1 (tiny, cache resident): the per-point
@@ -236,11 +269,6 @@ __global__ __launch_bounds__(256) void basis_rows(const T *__restrict__ tab, int
 //   ixs / rows: concatenated per variable; goff[iv] = first parameter of variable iv.
 // out[dep * total + flat]
 // ---------------------------------------------------------------------------------
-struct GridDims {
-    long long n[MAXI];     // grid points per variable
-    long long goff[MAXI];  // offset of variable iv in ixs / outside; rows offset = goff * order (see roff)
-    long long roff[MAXI];  // offset of variable iv in rows
-};
 
 template <typename T>
 __global__ __launch_bounds__(256) void grid_generic(const Desc<T> d, const T *__restrict__ gcoef,
@@ -319,6 +347,98 @@ __global__ __launch_bounds__(256) void grid_surface(const Desc<T> d, const T *__
         for (int dep = 0; dep < d.nDep; ++dep) {
             const T *__restrict__ c = gcoef + dep * d.cstride[0] + base;
             out[dep * total + flat] = contract2<T, O>(c, s0, b0, b1);
+        }
+    }
+}
+
+// Row-factored surface grid, compile-time order O for both variables, nDep <= 4 per pass.
+// One workgroup per grid row i0: its basis b0 is the same for every point of the row, so the
+// workgroup first contracts the FIRST variable for all columns of the coefficient table,
+//     rowc[dep][c] = sum_a b0[a] * C[dep][ix0 - O + a][c],     c in [0, nCoef1),
+// into LDS (nDep * nCoef1 values), and every grid point of the row then needs O values of rowc
+// per dependent variable: O multiply-adds instead of O * O, read from LDS addresses that
+// neighbouring lanes share (broadcast).  Lanes own VEC = 16 / sizeof(T) consecutive columns and
+// store 16 bytes per dependent variable when the rows are aligned.  The kernel is bound by its
+// stores (12 B fp32 / 24 B fp64 per point for nDep 3).  out[dep * total + i0 * n1 + i1]
+template <typename T, int O>
+__global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__restrict__ gcoef, const GridDims g,
+                                                 const int *__restrict__ ixs, const T *__restrict__ rows,
+                                                 const unsigned char *__restrict__ outside, T *__restrict__ out,
+                                                 unsigned long long *bad, const int vec_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    T *rowc = reinterpret_cast<T *>(smem_g);                  // [nDep][nCoef1]
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const long long n1 = g.n[1], total = g.n[0] * g.n[1];
+    const int nc1 = d.ncoef[1], s0 = d.cstride[1];
+    for (long long i0 = blockIdx.x; i0 < g.n[0]; i0 += gridDim.x) {
+        const int ix0 = ixs[g.goff[0] + i0];
+        const bool bad0 = outside[g.goff[0] + i0] != 0;
+        T b0[O];
+#pragma unroll
+        for (int a = 0; a < O; ++a) b0[a] = rows[g.roff[0] + i0 * O + a];
+        __syncthreads();                                       // the previous row's readers are done
+        for (int e = threadIdx.x; e < d.nDep * nc1; e += blockDim.x) {
+            const int dep = e / nc1, c = e - dep * nc1;
+            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - O) * s0 + c;
+            T acc = T(0);
+#pragma unroll
+            for (int a = 0; a < O; ++a) acc += b0[a] * col[a * s0];
+            rowc[e] = acc;
+        }
+        __syncthreads();
+        if (vec_ok) {
+            for (long long c0 = (long long)threadIdx.x * VEC; c0 < n1; c0 += (long long)blockDim.x * VEC) {
+                int ix1[VEC];
+                T b1[VEC][O];
+                bool anybad = bad0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    ix1[v] = ixs[g.goff[1] + c0 + v] - O;
+#pragma unroll
+                    for (int k = 0; k < O; ++k) b1[v][k] = rows[g.roff[1] + (c0 + v) * O + k];
+                    anybad |= outside[g.goff[1] + c0 + v] != 0;
+                }
+                if (anybad) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        if (bad0 | (outside[g.goff[1] + c0 + v] != 0)) record_bad(bad, i0 * n1 + c0 + v);
+                }
+                for (int dep = 0; dep < d.nDep; ++dep) {
+                    T res[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const T *rc = rowc + dep * nc1 + ix1[v];
+                        T acc = T(0);
+#pragma unroll
+                        for (int k = 0; k < O; ++k) acc += rc[k] * b1[v][k];
+                        res[v] = acc;
+                    }
+                    T *o = out + dep * total + i0 * n1 + c0;
+                    if constexpr (VEC == 4) {
+                        float4 w; w.x = res[0]; w.y = res[1]; w.z = res[2]; w.w = res[3];
+                        *reinterpret_cast<float4 *>(o) = w;
+                    } else {
+                        double2 w; w.x = res[0]; w.y = res[1];
+                        *reinterpret_cast<double2 *>(o) = w;
+                    }
+                }
+            }
+        } else {
+            for (long long i1 = threadIdx.x; i1 < n1; i1 += blockDim.x) {
+                const int ix1 = ixs[g.goff[1] + i1] - O;
+                T b1[O];
+#pragma unroll
+                for (int k = 0; k < O; ++k) b1[k] = rows[g.roff[1] + i1 * O + k];
+                if (bad0 | (outside[g.goff[1] + i1] != 0)) record_bad(bad, i0 * n1 + i1);
+                for (int dep = 0; dep < d.nDep; ++dep) {
+                    const T *rc = rowc + dep * nc1 + ix1;
+                    T acc = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) acc += rc[k] * b1[k];
+                    out[dep * total + i0 * n1 + i1] = acc;
+                }
+            }
         }
     }
 }

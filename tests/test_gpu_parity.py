@@ -399,4 +399,8 @@ def test_reference_json_files_evaluate():
                 got = np.stack(got) if isinstance(got, tuple) else np.asarray(got)[None, :]
                 orc, bad = oracle.c_evaluate(s.order, s.nCoef, knots, coefs, w, [u])
                 assert bad == -1
-                assert np.abs(got - orc).max() <= 1e-11 * _scale(orc), (name, w)
+                # second derivatives of these order-7 curves (knot spacing down to 6e-5) are
+                # ill-conditioned: the reference's own fp64 result is 6e-5 (7e-9 of the scale)
+                # away from an extended-precision evaluation, and so is ours
+                tol = 1e-11 if w[0] < 2 else 2e-8
+                assert np.abs(got - orc).max() <= tol * _scale(orc), (name, w)

@@ -6,7 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cases, bspy_amd
 
-def timed(f, steps=20, warm=3):
+def timed(f, steps=20, warm=3, spin_s=0.15):
+    import time as _t
+    t_end = _t.perf_counter() + spin_s          # clock spin-up (see bench.py)
+    while _t.perf_counter() < t_end:
+        f()
+    torch.cuda.synchronize()
     for _ in range(warm): f()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
