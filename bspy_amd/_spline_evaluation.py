@@ -124,6 +124,47 @@ def jacobian(self, uvw):
     return out[:, :, 0].astype(self.coefs.dtype, copy=False)
 
 
+def normal(self, uvw, normalize=True, indices=None):
+    """Reference bspy/_spline_evaluation.py:215-246: the normal at one point, or (extension)
+    at arrays of points -> shape (len(indices or all), *broadcast_shape)."""
+    if abs(self.nInd - self.nDep) != 1:
+        raise ValueError("The number of independent variables must be one different than the number of dependent variables.")
+    negate = bool(getattr(self, "metadata", {}).get("negateNormal", False))
+    batched = len(uvw) == self.nInd and self.nInd > 0 and not np.isscalar(uvw[0]) and \
+        (uvw[0].ndim if hasattr(uvw[0], "ndim") else np.ndim(uvw[0])) > 0
+    if batched:
+        if any(_is_torch(a) for a in uvw):
+            import torch
+            dev = next(a for a in uvw if _is_torch(a) and a.is_cuda).device
+            ts = torch.broadcast_tensors(*[(a if _is_torch(a) else torch.as_tensor(np.asarray(a))).to(dev) for a in uvw])
+            shape = tuple(ts[0].shape)
+            try:
+                out = device_tables(self, dev.index).normal_device(ts, normalize, negate)
+            except nv.DomainError as e:
+                cpu = [t.reshape(-1)[e.index].item() for t in ts]
+                raise ValueError(f"Spline evaluation outside domain: {np.atleast_1d(cpu)}") from None
+            out = out.view((out.shape[0], *shape))
+        else:
+            arrays = [np.asarray(a) for a in uvw]
+            shape = np.broadcast_shapes(*[a.shape for a in arrays])
+            flat = [np.ascontiguousarray(np.broadcast_to(a, shape), compute_dtype(self)).reshape(-1) for a in arrays]
+            try:
+                out = device_tables(self).normal(flat, normalize, negate)
+            except nv.DomainError as e:
+                raise ValueError(_domain_message(arrays, shape, e.index)) from None
+            out = out.reshape((out.shape[0], *shape)).astype(self.coefs.dtype, copy=False)
+        return out if indices is None else out[list(indices)]
+    uvw = np.atleast_1d(uvw)
+    if len(uvw) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
+    try:
+        out = device_tables(self).normal([uvw[i:i + 1] for i in range(self.nInd)], normalize, negate)
+    except nv.DomainError:
+        raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
+    out = out[:, 0].astype(self.coefs.dtype, copy=False)
+    return out if indices is None else out[list(indices)]
+
+
 # --------------------------------------------------------------------------------------
 # batched entry points
 # --------------------------------------------------------------------------------------

@@ -917,6 +917,77 @@ extern "C" bsk_status bsk_jacobian(bsk_spline s, const void *const *uvw, int64_t
 }
 
 // ------------------------------------------------------------------------------------
+// normal
+// ------------------------------------------------------------------------------------
+template <typename T>
+static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, bsk_mem mem, int normalize, int negate,
+                             void *out, hipStream_t st, int64_t *first_bad)
+{
+    const int big = std::max(s->nInd, s->nDep);
+    if (first_bad) *first_bad = -1;
+    if (n == 0) return BSK_OK;
+    const long long chunk = mem == BSK_HOST ? std::min(n, HOST_CHUNK) : n;
+    // jacobian workspace (device) for one chunk
+    HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
+    T *djac = static_cast<T *>(s->aux_ws.p);
+    T *din = nullptr, *dout = static_cast<T *>(out);
+    if (mem == BSK_HOST) {
+        HIPCHK(s->in_ws.reserve(sizeof(T) * (size_t)chunk * s->nInd));
+        HIPCHK(s->out_ws.reserve(sizeof(T) * (size_t)chunk * big));
+        din = static_cast<T *>(s->in_ws.p);
+        dout = static_cast<T *>(s->out_ws.p);
+    }
+    for (long long start = 0; start < n; start += chunk) {
+        const long long m = std::min(chunk, n - start);
+        Params<T> prm;
+        for (int iv = 0; iv < MAXI; ++iv) prm.p[iv] = nullptr;
+        for (int iv = 0; iv < s->nInd; ++iv) {
+            if (mem == BSK_HOST) {
+                HIPCHK(hipMemcpyAsync(din + (size_t)iv * m, static_cast<const T *>(uvw[iv]) + start, sizeof(T) * (size_t)m,
+                                      hipMemcpyHostToDevice, st));
+                prm.p[iv] = din + (size_t)iv * m;
+            } else {
+                prm.p[iv] = static_cast<const T *>(uvw[iv]);
+            }
+        }
+        bsk_status r = dispatch_jac<T>(s, prm, m, djac, st);
+        if (r != BSK_OK) return r;
+        const int block = 256;
+        const int grid = (int)std::max<long long>(1, std::min<long long>((m + block - 1) / block, (long long)s->num_cu * 8));
+        hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(block), 0, st, djac, s->nInd, s->nDep, m, normalize, negate,
+                           dout);
+        HIPCHK(hipGetLastError());
+        if (mem == BSK_HOST) {
+            for (int row = 0; row < big; ++row)
+                HIPCHK(hipMemcpyAsync(static_cast<T *>(out) + (size_t)row * n + start, dout + (size_t)row * m,
+                                      sizeof(T) * (size_t)m, hipMemcpyDeviceToHost, st));
+            int64_t bad = -1;
+            r = read_bad(s, st, &bad);
+            if (r == BSK_ERR_DOMAIN) {
+                if (first_bad) *first_bad = start + bad;
+                return r;
+            }
+            if (r != BSK_OK) return r;
+        }
+    }
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_normal(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem mem, int normalize, int negate,
+                                 void *out, void *stream, int64_t *first_bad)
+{
+    bsk_status r = check_call(s, uvw, n, out);
+    if (r != BSK_OK) return r;
+    if (std::abs(s->nInd - s->nDep) != 1)
+        return fail(BSK_ERR_INVALID, "The number of independent variables must be one different than the number of dependent variables.");
+    if (std::max(s->nInd, s->nDep) > 4) return fail(BSK_ERR_UNSUPPORTED, "normal supports max(nInd, nDep) <= 4");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32 ? run_normal<float>(s, uvw, n, mem, normalize, negate, out, st, first_bad)
+                               : run_normal<double>(s, uvw, n, mem, normalize, negate, out, st, first_bad);
+}
+
+// ------------------------------------------------------------------------------------
 // tensor-product grid
 // ------------------------------------------------------------------------------------
 template <typename T>

@@ -443,4 +443,79 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
     }
 }
 
+// ---------------------------------------------------------------------------------
+// normal from a batched jacobian (next row: reference bspy/_spline_evaluation.py:215-246).
+// |nInd - nDep| == 1, big = max(nInd, nDep) <= 4.  jac[(dep * nInd + j) * N + n] (the layout
+// bsk_jacobian writes); the tangent space is taken with its larger dimension first,
+// normal[i] = sign * (-1)^i * det(tangent space without row i); out[i * N + n].
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T det_small(const T (&a)[9], int m)
+{
+    if (m == 0) return T(1);
+    if (m == 1) return a[0];
+    if (m == 2) return a[0] * a[3] - a[1] * a[2];
+    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+
+template <typename T>
+__device__ __forceinline__ void normal_from_tangents(const T (&tan)[4][3], int big, bool normalize, bool negate, T (&nrm)[4])
+{
+    const int small = big - 1;
+    T sumsq = T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nrm[i] = T(0);
+        if (i < big) {
+            T sub[9];
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < big && r != i) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < small) sub[q++] = tan[r][c];
+                }
+            }
+            T v = det_small<T>(sub, small);
+            if (i & 1) v = -v;
+            if (negate) v = -v;
+            nrm[i] = v;
+            sumsq += v * v;
+        }
+    }
+    if (normalize) {
+        const T len = sqrt(sumsq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nrm[i] = nrm[i] / len;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normal_epilogue(const T *__restrict__ jac, int nInd, int nDep, long long N,
+                                                       int normalize, int negate, T *__restrict__ out)
+{
+    const int big = nInd > nDep ? nInd : nDep, small = big - 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T tan[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                tan[r][c] = T(0);
+                if (r < big && c < small) {
+                    // jacobian entry (dep, j): dep = row of the (nDep x nInd) matrix
+                    const int dep = nInd > nDep ? c : r, j = nInd > nDep ? r : c;
+                    tan[r][c] = jac[((long long)dep * nInd + j) * N + n];
+                }
+            }
+        T nrm[4];
+        normal_from_tangents<T>(tan, big, normalize != 0, negate != 0, nrm);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < big) out[(long long)i * N + n] = nrm[i];
+    }
+}
+
 }  // namespace bsk

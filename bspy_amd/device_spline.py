@@ -125,6 +125,33 @@ class DeviceSpline:
         nv.check(st, bad)
         return out
 
+    def normal(self, points, normalize=True, negate=False):
+        """points: nInd arrays of N values -> ndarray (max(nInd, nDep), N) of normals
+        (|nInd - nDep| must be 1)."""
+        ps, n = self._host_params(points)
+        out = np.empty((max(self.nInd, self.nDep), n), self.dtype)
+        bad = ctypes.c_int64(-1)
+        st = nv.lib().bsk_normal(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
+                                 1 if normalize else 0, 1 if negate else 0, out.ctypes.data, None, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
+    def normal_device(self, points, normalize=True, negate=False, out=None, check=True):
+        """points: nInd CUDA tensors -> CUDA tensor (max(nInd, nDep), N)."""
+        torch, tdt, ps, n = self._torch_params(points)
+        big = max(self.nInd, self.nDep)
+        if out is None:
+            out = torch.empty((big, n), dtype=tdt, device=ps[0].device)
+        elif out.dtype != tdt or out.numel() != big * n or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (max(nInd, nDep), N) tensor of the spline's dtype")
+        st = nv.lib().bsk_normal(self._handle, nv.ptr_array([p.data_ptr() for p in ps]), n, nv.BSK_DEVICE,
+                                 1 if normalize else 0, 1 if negate else 0, out.data_ptr(),
+                                 self._stream_ptr(torch, self.device), None)
+        nv.check(st)
+        if check:
+            self.domain_status()
+        return out
+
     def evaluate_grid(self, axes, wrt=None):
         """axes: nInd 1-D arrays (n_i values) -> ndarray (nDep, n_0, ..., n_{nInd-1})."""
         if len(axes) != self.nInd:

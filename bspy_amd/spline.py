@@ -8,6 +8,7 @@ error messages for
     s.derivative(with_respect_to, *uvw)                           spline.py:720-770
     s.jacobian(uvw) / s.tangent_space(uvw)                        spline.py:1354-1377, :2238-2252
     s.domain()                                                    spline.py:794-808
+    s.normal(uvw, normalize=True, indices=None)                   spline.py:1648-1682
     Spline.bspline_values(knot, knots, splineOrder, u, ...)       spline.py:207-252
     to_dict / from_dict / load / save (JSON, as an input format)   spline.py:1099-1125, :1542-1583, :1998-2026, :2254-2267
 
@@ -136,6 +137,12 @@ class Spline:
                 return out
             return out.astype(self.coefs.dtype, copy=False)
         return _ev.jacobian(self, uvw)
+
+    def normal(self, uvw, normalize=True, indices=None):
+        """Normal of the spline (|nInd - nDep| must be 1; reference spline.py:1648-1682): unit
+        length by default, else the area-scaled cofactor vector; `metadata["negateNormal"]`
+        flips it.  Extension: nInd arrays of points -> (len(normal), *shape)."""
+        return _ev.normal(self, uvw, normalize, indices)
 
     def tangent_space(self, uvw):
         """Same as jacobian (reference spline.py:2238-2252)."""

@@ -101,6 +101,17 @@ bsk_status bsk_jacobian(bsk_spline s, const void *const *uvw, int64_t n,
                         bsk_mem mem, void *out, void *stream, int64_t *first_bad);
 
 /*
+ * Batched normal (next row of the scope table).
+ * Replaces: Spline.normal, bspy/spline.py:1648-1682 -> bspy/_spline_evaluation.py:215-246
+ *   (single point in the reference).  Needs |nInd - nDep| == 1 and max(nInd, nDep) <= 4.
+ *   normalize  : unit length (the reference's default) or area-scaled cofactor vector
+ *   negate     : the reference's metadata["negateNormal"]
+ *   out        : max(nInd, nDep) * n values, out[i * n + p]
+ */
+bsk_status bsk_normal(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem mem, int normalize, int negate,
+                      void *out, void *stream, int64_t *first_bad);
+
+/*
  * Tensor-product grid evaluation: parameters are the outer product of per-variable
  * vectors (the reference's broadcast call s(u[:, None], v[None, :]), bspy/spline.py:941-945).
  *   grid[iv]   : ngrid[iv] values of variable iv

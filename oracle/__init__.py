@@ -48,6 +48,7 @@ def _lib():
             getattr(_LIB, "orc_bspline_values_" + suf).restype = ctypes.c_int
             getattr(_LIB, "orc_evaluate_" + suf).restype = ctypes.c_long
             getattr(_LIB, "orc_jacobian_" + suf).restype = ctypes.c_long
+            getattr(_LIB, "orc_normal_" + suf).restype = ctypes.c_long
     return _LIB
 
 
@@ -197,3 +198,38 @@ def c_jacobian(order, nCoef, knots, coefs, points):
         ctypes.c_int(len(order)), ctypes.c_int(cf.shape[0]), o, c, kp, cf.ctypes.data_as(ctypes.POINTER(ct)),
         pp, ctypes.c_long(n), out.ctypes.data_as(ctypes.POINTER(ct)))
     return out, int(bad)
+
+
+def c_normal(order, nCoef, knots, coefs, points, normalize=True, negate=False):
+    """Batched normal (bspy/_spline_evaluation.py:215-246).  Returns (out (max(nInd, nDep), N),
+    first_bad_index or -1)."""
+    dt, suf, ct, ks, cf, ps, kp, pp, o, c, IntArr = _prep(order, nCoef, knots, coefs, points)
+    n = len(ps[0]) if ps else 1
+    big = max(len(order), cf.shape[0])
+    out = np.zeros((big, n), dt)
+    bad = getattr(_lib(), "orc_normal_" + suf)(
+        ctypes.c_int(len(order)), ctypes.c_int(cf.shape[0]), o, c, kp, cf.ctypes.data_as(ctypes.POINTER(ct)),
+        pp, ctypes.c_long(n), ctypes.c_int(1 if normalize else 0), ctypes.c_int(1 if negate else 0),
+        out.ctypes.data_as(ctypes.POINTER(ct)))
+    return out, int(bad)
+
+
+def py_normal(order, nCoef, knots, coefs, uvw, normalize=True, negate=False, indices=None):
+    """_spline_evaluation.py:215-246, one point."""
+    nInd, nDep = len(order), coefs.shape[0]
+    if abs(nInd - nDep) != 1:
+        raise ValueError("The number of independent variables must be one different than the number of dependent variables.")
+    tangentSpace = py_jacobian(order, nCoef, knots, coefs, uvw)
+    if nInd > nDep:
+        big = nInd
+        tangentSpace = tangentSpace.T
+    else:
+        big = nDep
+    sign = -1 if negate else 1
+    idx = range(big) if indices is None else indices
+    normal = np.empty(len(idx), coefs.dtype)
+    for k, i in enumerate(idx):
+        normal[k] = sign * ((-1) ** i) * np.linalg.det(tangentSpace[[j for j in range(big) if i != j]])
+    if normalize:
+        normal /= np.linalg.norm(normal)
+    return normal

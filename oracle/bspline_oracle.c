@@ -9,6 +9,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product (bspy_amd/) never links, imports or calls it.
  */
+#include <math.h>
 #include <stdlib.h>
 
 #define ORC_MAX_NIND 8

@@ -166,6 +166,59 @@ long FN(orc_jacobian)(int nInd, int nDep, const int *order, const int *nCoef,
     return bad;
 }
 
+/* Determinant of the m x m matrix a (row major, m <= 3); m == 0 gives 1 (np.linalg.det of a
+ * 0 x 0 matrix). */
+static REAL FN(orc_det)(const REAL *a, int m)
+{
+    if (m == 0) return (REAL)1;
+    if (m == 1) return a[0];
+    if (m == 2) return a[0] * a[3] - a[1] * a[2];
+    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+
+/* Batched normal (bspy/_spline_evaluation.py:215-246): |nInd - nDep| == 1, max(nInd, nDep) <= 4.
+ * out[i * N + n], i < max(nInd, nDep).  negate = metadata["negateNormal"]. */
+long FN(orc_normal)(int nInd, int nDep, const int *order, const int *nCoef, const REAL *const *knots,
+                    const REAL *coefs, const REAL *const *uvw, long N, int normalize, int negate, REAL *out)
+{
+    const int big = nInd > nDep ? nInd : nDep, small = big - 1;
+    REAL *jac = (REAL *)malloc(sizeof(REAL) * (size_t)nDep * nInd);
+    const REAL *one_pt[ORC_MAX_NIND];
+    REAL p[ORC_MAX_NIND];
+    long bad = -1;
+    for (long n = 0; n < N; ++n) {
+        for (int iv = 0; iv < nInd; ++iv) { p[iv] = uvw[iv][n]; one_pt[iv] = &p[iv]; }
+        if (FN(orc_jacobian)(nInd, nDep, order, nCoef, knots, coefs, one_pt, 1, jac) >= 0) { bad = n; break; }   /* :220 */
+        /* tangent space with the larger dimension first (:223-228): T[r][c], r < big, c < small */
+        REAL T[4][3];
+        for (int r = 0; r < big; ++r)
+            for (int c = 0; c < small; ++c)
+                T[r][c] = nInd > nDep ? jac[c * nInd + r] : jac[r * nInd + c];     /* jac is (nDep, nInd) */
+        REAL nrm[4];
+        REAL sumsq = (REAL)0;
+        for (int i = 0; i < big; ++i) {                                            /* :239-240 */
+            REAL sub[9];
+            int q = 0;
+            for (int r = 0; r < big; ++r) {
+                if (r == i) continue;
+                for (int c = 0; c < small; ++c) sub[q++] = T[r][c];
+            }
+            REAL v = FN(orc_det)(sub, small);
+            if (i & 1) v = -v;
+            if (negate) v = -v;
+            nrm[i] = v;
+            sumsq += v * v;
+        }
+        if (normalize) {                                                           /* :243-244 */
+            const double len = sqrt((double)sumsq);
+            for (int i = 0; i < big; ++i) nrm[i] = (REAL)((double)nrm[i] / len);
+        }
+        for (int i = 0; i < big; ++i) out[(long)i * N + n] = nrm[i];
+    }
+    free(jac);
+    return bad;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

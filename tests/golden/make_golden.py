@@ -109,6 +109,20 @@ def run_case(bspy, c):
         for i in range(c.n):
             jac[i] = s.jacobian([p[i] for p in c.points])
         out["jac"] = jac
+    if abs(c.nInd - c.nDep) == 1 and max(c.nInd, c.nDep) <= 4:
+        # Spline.normal (bspy/_spline_evaluation.py:215-246): unit and area-scaled, first 128 points
+        m = min(c.n, 128)
+        big = max(c.nInd, c.nDep)
+        nu = np.empty((m, big), c.coefs.dtype)
+        na = np.empty((m, big), c.coefs.dtype)
+        flipped = bspy.Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs, {"negateNormal": True})
+        nf = np.empty((m, big), c.coefs.dtype)
+        for i in range(m):
+            uvw = [p[i] for p in c.points]
+            nu[i] = s.normal(uvw)
+            na[i] = s.normal(uvw, False)
+            nf[i] = flipped.normal(uvw, False)
+        out["normal_unit"], out["normal_area"], out["normal_area_negated"] = nu, na, nf
     return out
 
 

@@ -404,3 +404,35 @@ def test_reference_json_files_evaluate():
                 # away from an extended-precision evaluation, and so is ours
                 tol = 1e-11 if w[0] < 2 else 2e-8
                 assert np.abs(got - orc).max() <= tol * _scale(orc), (name, w)
+
+
+NORMAL_CASES = [n for n, c in CASES.items() if abs(c.nInd - c.nDep) == 1 and max(c.nInd, c.nDep) <= 4]
+
+
+@pytest.mark.parametrize("name", sorted(NORMAL_CASES))
+def test_normal_against_reference(name, golden_parity):
+    """Batched Spline.normal against the reference's single-point normal."""
+    c = CASES[name]
+    m = golden_parity[f"{name}/normal_unit"].shape[0]
+    pts = [p[:m] for p in c.points]
+    tol = 5e-5 if (c.knots[0].dtype == np.float32 or c.coefs.dtype == np.float32) else 1e-11
+    for key, normalize, meta in (("normal_unit", True, {}), ("normal_area", False, {}),
+                                 ("normal_area_negated", False, {"negateNormal": True})):
+        s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs, meta)
+        ref = golden_parity[f"{name}/{key}"].T
+        out = s.normal(pts, normalize)
+        assert out.shape == ref.shape
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), (name, key)
+        if not np.isnan(ref).all():
+            assert np.nanmax(np.abs(out - ref)) <= tol * max(1.0, float(np.nanmax(np.abs(ref)))), (name, key)
+        orc, bad = oracle.c_normal(c.order, c.nCoef, c.knots, c.coefs, pts, normalize, bool(meta))
+        if not np.isnan(orc).all():
+            assert np.nanmax(np.abs(out - orc)) <= tol * max(1.0, float(np.nanmax(np.abs(orc))))
+    if c.order[0] > 1:
+        s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+        one = s.normal([float(p[3]) for p in c.points])               # single point, reference call style
+        assert one.shape == (max(c.nInd, c.nDep),)
+        assert np.abs(one - golden_parity[f"{name}/normal_unit"][3]).max() <= tol
+        assert np.array_equal(s.normal([float(p[3]) for p in c.points], indices=(1, 0)), one[[1, 0]])
+    with pytest.raises(ValueError, match="one different"):
+        Spline(2, 2, [2, 2], [2, 2], [[0, 0, 1, 1.0]] * 2, np.zeros((2, 2, 2))).normal([0.5, 0.5])

@@ -133,3 +133,28 @@ def test_span_and_errors(golden_api):
     assert bad == -1 and np.isnan(out).all()             # NaN passes the domain check
     out, bad = oracle.c_evaluate([4], [7], [k], coefs, [4], [np.array([0.5])])
     assert (out == 0).all()                             # derivativeOrder >= order -> exact zeros
+
+
+NORMAL_CASES = [n for n, c in CASES.items() if abs(c.nInd - c.nDep) == 1 and max(c.nInd, c.nDep) <= 4]
+
+
+@pytest.mark.parametrize("name", sorted(NORMAL_CASES))
+def test_normal_oracle_against_reference(name, golden_parity):
+    """Oracle normal (next row 8f-1) against Spline.normal of the reference: unit, area-scaled
+    and with metadata negateNormal."""
+    c = CASES[name]
+    m = golden_parity[f"{name}/normal_unit"].shape[0]
+    pts = [p[:m] for p in c.points]
+    tol = 5e-5 if (c.knots[0].dtype == np.float32 or c.coefs.dtype == np.float32) else 1e-12
+    for key, normalize, negate in (("normal_unit", True, False), ("normal_area", False, False),
+                                   ("normal_area_negated", False, True)):
+        ref = golden_parity[f"{name}/{key}"].T                     # (big, m)
+        out, bad = oracle.c_normal(c.order, c.nCoef, c.knots, c.coefs, pts, normalize, negate)
+        assert bad == -1
+        # an order-1 curve has zero tangent: the unit normal is 0/0 = NaN in the reference too
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), (name, key)
+        if not np.isnan(ref).all():
+            assert np.nanmax(np.abs(out - ref)) <= tol * max(1.0, float(np.nanmax(np.abs(ref)))), (name, key)
+    if c.coefs.dtype == np.float64 and c.order[0] > 1:
+        r = oracle.py_normal(c.order, c.nCoef, c.knots, c.coefs, [float(p[3]) for p in c.points])
+        assert np.abs(r - golden_parity[f"{name}/normal_unit"][3]).max() <= 1e-12
