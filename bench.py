@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_POINTS = 10_000_000
-BYTES_PER_EVAL = {"evaluate": 40, "derivative": 40, "jacobian": 64}
+BYTES_PER_EVAL = {"evaluate": 40, "derivative": 40, "jacobian": 64, "normal": 40}
 
 
 def cpu_baseline(order, ncoef, knots, coefs, sample):
@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian"], default="evaluate")
+    ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian", "normal"], default="evaluate")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
@@ -137,6 +137,8 @@ def main():
     def step():
         if args.op == "jacobian":
             st = lib.bsk_jacobian(handle, uvw_ptrs, n, nv.BSK_DEVICE, out_ptr, stream_ptr, None)
+        elif args.op == "normal":
+            st = lib.bsk_normal(handle, uvw_ptrs, n, nv.BSK_DEVICE, 1, 0, out_ptr, stream_ptr, None)
         else:
             st = lib.bsk_evaluate(handle, wrt_arr, uvw_ptrs, n, nv.BSK_DEVICE, out_ptr, stream_ptr, None)
         if st != 0:
@@ -210,7 +212,7 @@ def main():
                        "points_per_gpu": n, "op": args.op, "sharding": "point batch sharded per rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.op, n),
-                         "kernel": "eval_rowrot<double,4>" if args.op != "jacobian" else "jac_stream<double,2,4>",
+                         "kernel": {"jacobian": "jac_rowrot<double,4,false>", "normal": "jac_rowrot<double,4,true>"}.get(args.op, "eval_rowrot<double,4>"),
                          "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_eval": bpe,
                          "algorithmic_bytes_per_launch": bpe * n,
                          "measured_stream_floor_GBs": 5960.0},

@@ -739,32 +739,52 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
     return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
 }
 
+// jac_rowrot / fused normal: surfaces of order 2 or 4 whose odd-stride image fits LDS
+template <typename T>
+static size_t rowrot_lds_bytes(bsk_spline s)
+{
+    const TileDesc<T> &tdr = tile_of<T>(s);
+    const size_t rs = (size_t)(s->ncoef[1] | 1);
+    const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
+    return (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
+}
+
+template <typename T>
+static bool rowrot_applies(bsk_spline s)
+{
+    return has_fixed_path(s) && s->nInd == 2 && (s->order[0] == 2 || s->order[0] == 4) &&
+           (s->variant == 0 || s->variant == 9) && rowrot_lds_bytes<T>(s) <= s->lds_max;
+}
+
+template <typename T, bool NORMAL>
+static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long long n, T *out, int normalize, int negate,
+                                    hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const TileDesc<T> &tdr = tile_of<T>(s);
+    const size_t lds_rr = rowrot_lds_bytes<T>(s);
+    const long long nt = (n + TILE - 1) / TILE;
+    const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    if (s->order[0] == 4) {
+        HIPCHK(allow_lds(jac_rowrot<T, 4, NORMAL>, lds_rr));
+        hipLaunchKernelGGL((jac_rowrot<T, 4, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
+                           s->bad, normalize, negate);
+    } else {
+        HIPCHK(allow_lds(jac_rowrot<T, 2, NORMAL>, lds_rr));
+        hipLaunchKernelGGL((jac_rowrot<T, 2, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
+                           s->bad, normalize, negate);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
 template <typename T>
 static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
-    if (has_fixed_path(s) && s->nInd == 2 && (s->order[0] == 2 || s->order[0] == 4) && (s->variant == 0 || s->variant == 9)) {
-        const TileDesc<T> &tdr = tile_of<T>(s);
-        const size_t rs = (size_t)(s->ncoef[1] | 1);
-        const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
-        const size_t lds_rr = (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
-        if (lds_rr <= s->lds_max) {
-            const Desc<T> &d = desc_of<T>(s);
-            const long long nt = (n + TILE - 1) / TILE;
-            const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
-            const T *tab = static_cast<const T *>(s->tab);
-            const T *coef = static_cast<const T *>(s->coef);
-            if (s->order[0] == 4) {
-                HIPCHK(allow_lds(jac_rowrot<T, 4>, lds_rr));
-                hipLaunchKernelGGL((jac_rowrot<T, 4>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out, s->bad);
-            } else {
-                HIPCHK(allow_lds(jac_rowrot<T, 2>, lds_rr));
-                hipLaunchKernelGGL((jac_rowrot<T, 2>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out, s->bad);
-            }
-            HIPCHK(hipGetLastError());
-            return BSK_OK;
-        }
-    }
+    if (rowrot_applies<T>(s)) return launch_jac_rowrot<T, false>(s, prm, n, out, 0, 0, st);
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         const size_t lds = tile_lds_bytes<T>(s, false);
         if (lds != 0) {
@@ -927,8 +947,9 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
     if (first_bad) *first_bad = -1;
     if (n == 0) return BSK_OK;
     const long long chunk = mem == BSK_HOST ? std::min(n, HOST_CHUNK) : n;
-    // jacobian workspace (device) for one chunk
-    HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
+    // jacobian workspace (device) for one chunk, unless the normal is fused into the jacobian kernel
+    const bool fused = s->nDep == 3 && rowrot_applies<T>(s);
+    if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
     T *djac = static_cast<T *>(s->aux_ws.p);
     T *din = nullptr, *dout = static_cast<T *>(out);
     if (mem == BSK_HOST) {
@@ -950,13 +971,20 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
                 prm.p[iv] = static_cast<const T *>(uvw[iv]);
             }
         }
-        bsk_status r = dispatch_jac<T>(s, prm, m, djac, st);
-        if (r != BSK_OK) return r;
-        const int block = 256;
-        const int grid = (int)std::max<long long>(1, std::min<long long>((m + block - 1) / block, (long long)s->num_cu * 8));
-        hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(block), 0, st, djac, s->nInd, s->nDep, m, normalize, negate,
-                           dout);
-        HIPCHK(hipGetLastError());
+        bsk_status r;
+        if (fused) {
+            // surface in 3-D on the LDS image: tangents never leave the registers
+            r = launch_jac_rowrot<T, true>(s, prm, m, dout, normalize, negate, st);
+            if (r != BSK_OK) return r;
+        } else {
+            r = dispatch_jac<T>(s, prm, m, djac, st);
+            if (r != BSK_OK) return r;
+            const int block = 256;
+            const int grid = (int)std::max<long long>(1, std::min<long long>((m + block - 1) / block, (long long)s->num_cu * 8));
+            hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(block), 0, st, djac, s->nInd, s->nDep, m, normalize,
+                               negate, dout);
+            HIPCHK(hipGetLastError());
+        }
         if (mem == BSK_HOST) {
             for (int row = 0; row < big; ++row)
                 HIPCHK(hipMemcpyAsync(static_cast<T *>(out) + (size_t)row * n + start, dout + (size_t)row * m,

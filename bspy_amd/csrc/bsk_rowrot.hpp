@@ -115,11 +115,15 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 // Per dependent variable the window is read once; every row gives t_a = sum_k c[a][k] b1[k] and
 // td_a = sum_k c[a][k] db1[k]; du = sum_a t_a db0[a] and dv = sum_a td_a b0[a] are combined with
 // the rotation-invariant tree.  out[(dep * 2 + j) * N + n]
-template <typename T, int O>
+// NORMAL = true (surfaces in 3-D, nDep == 3): the two tangents stay in registers and the kernel
+// writes the normal (cross product, reference bspy/_spline_evaluation.py:215-246: optional unit
+// length, optional negation) instead of the six partials: out[i * N + n], i < 3.
+template <typename T, int O, bool NORMAL>
 __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                    const T *__restrict__ gcoef, const Params<T> prm,
-                                                   const long long N, T *__restrict__ out, unsigned long long *bad)
+                                                   const long long N, T *__restrict__ out, unsigned long long *bad,
+                                                   const int normalize, const int negate)
 {
     static_assert(O == 2 || O == 4, "row rotation covers orders 2 and 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,7 +189,10 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
         for (int a = 0; a < O; ++a)
             ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
 
-        for (int dep = 0; dep < d.nDep; ++dep) {
+        T su[3], sv[3];                    // NORMAL: the two tangent vectors
+        const int ndep = NORMAL ? 3 : d.nDep;
+#pragma unroll 3
+        for (int dep = 0; dep < ndep; ++dep) {
             T c[O][O];
 #pragma unroll
             for (int a = 0; a < O; ++a) lds_issue_row<T, O>(ra[a], c[a]);
@@ -199,16 +206,39 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
                 qu[a] = mul_rn<T>(t, db0r[a]);
                 qv[a] = mul_rn<T>(tdv, b0r[a]);
             }
-            T *o = out + (long long)dep * 2 * N + n;
+            T du, dv;
             if constexpr (O == 2) {
-                o[0] = add_rn<T>(qu[0], qu[1]);
-                o[N] = add_rn<T>(qv[0], qv[1]);
+                du = add_rn<T>(qu[0], qu[1]);
+                dv = add_rn<T>(qv[0], qv[1]);
             } else {
-                o[0] = add_rn<T>(add_rn<T>(qu[0], qu[2]), add_rn<T>(qu[1], qu[3]));
-                o[N] = add_rn<T>(add_rn<T>(qv[0], qv[2]), add_rn<T>(qv[1], qv[3]));
+                du = add_rn<T>(add_rn<T>(qu[0], qu[2]), add_rn<T>(qu[1], qu[3]));
+                dv = add_rn<T>(add_rn<T>(qv[0], qv[2]), add_rn<T>(qv[1], qv[3]));
+            }
+            if constexpr (NORMAL) {
+                if (dep == 0) { su[0] = du; sv[0] = dv; }
+                else if (dep == 1) { su[1] = du; sv[1] = dv; }
+                else { su[2] = du; sv[2] = dv; }
+            } else {
+                T *o = out + (long long)dep * 2 * N + n;
+                o[0] = du;
+                o[N] = dv;
             }
 #pragma unroll
             for (int a = 0; a < O; ++a) ra[a] += dstride;
+        }
+        if constexpr (NORMAL) {
+            // cofactors of the 3 x 2 tangent space: normal[i] = (-1)^i det(rows != i)
+            T nx = su[1] * sv[2] - sv[1] * su[2];
+            T ny = -(su[0] * sv[2] - sv[0] * su[2]);
+            T nz = su[0] * sv[1] - sv[0] * su[1];
+            if (negate) { nx = -nx; ny = -ny; nz = -nz; }
+            if (normalize) {
+                const T len = sqrt(nx * nx + ny * ny + nz * nz);
+                nx = nx / len; ny = ny / len; nz = nz / len;
+            }
+            out[n] = nx;
+            out[N + n] = ny;
+            out[2 * N + n] = nz;
         }
     }
 }
