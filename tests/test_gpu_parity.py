@@ -436,3 +436,26 @@ def test_normal_against_reference(name, golden_parity):
         assert np.array_equal(s.normal([float(p[3]) for p in c.points], indices=(1, 0)), one[[1, 0]])
     with pytest.raises(ValueError, match="one different"):
         Spline(2, 2, [2, 2], [2, 2], [[0, 0, 1, 1.0]] * 2, np.zeros((2, 2, 2))).normal([0.5, 0.5])
+
+
+def test_collocation_matrix():
+    """Batched collocation matrix against the reference's row loop
+    (bspy/_spline_fitting.py:736-751) restated with the oracle, Hermite rows included."""
+    rng = np.random.default_rng(9)
+    for order, ncoef, dt in ((4, 12, np.float64), (6, 30, np.float64), (3, 9, np.float32)):
+        knots = cases.nonuniform_knots(rng, order, ncoef, dt, 0.0, 1.0)
+        u = np.sort(rng.random(40).astype(dt))
+        u = np.concatenate(([knots[order - 1]] * 2, u, u[5:7], u[5:7], [knots[ncoef]] * 3)).astype(dt)
+        u = np.sort(u, kind="stable")
+        A = bspy_amd.collocation_matrix(knots, order, u)
+        ref = np.zeros((len(u), ncoef), dt)
+        prev, deriv = None, 0
+        for i, x in enumerate(u):
+            deriv = deriv + 1 if (prev is not None and x == prev) else 0
+            prev = x
+            ix, row = oracle.c_bspline_values(None, knots, order, x, deriv)
+            ref[i, ix - order:ix] = row
+        assert A.shape == ref.shape and A.dtype == ref.dtype
+        assert np.abs(A - ref).max() <= (1e-4 if dt == np.float32 else 1e-11) * max(1.0, np.abs(ref).max())
+        first, rows = bspy_amd.collocation_matrix(knots, order, u, dense=False)
+        assert np.array_equal(A[np.arange(len(u))[:, None], first[:, None] + np.arange(order)], rows)

@@ -235,3 +235,9 @@ def test_json_round_trip_and_reference_files(tmp_path):
     assert np.array_equal(back[1].coefs, s.coefs)
     d = a.to_dict()
     assert d["type"] == "Spline" and Spline.from_dict(d).nDep == 3
+
+
+def test_collocation_derivative_orders():
+    from bspy_amd.collocation import derivative_orders
+    assert derivative_orders([0, 0, 0.1, 0.2, 0.2, 0.2, 0.3]).tolist() == [0, 1, 0, 0, 1, 2, 0]
+    assert derivative_orders([]).tolist() == []
