@@ -459,3 +459,31 @@ def test_collocation_matrix():
         assert np.abs(A - ref).max() <= (1e-4 if dt == np.float32 else 1e-11) * max(1.0, np.abs(ref).max())
         first, rows = bspy_amd.collocation_matrix(knots, order, u, dense=False)
         assert np.array_equal(A[np.arange(len(u))[:, None], first[:, None] + np.arange(order)], rows)
+
+
+def test_hip_graph_capture_of_device_calls():
+    """BSK_DEVICE calls only enqueue kernels on the given stream (no allocation, no sync after
+    the first call), so they can be captured into a HIP graph and replayed."""
+    torch = pytest.importorskip("torch")
+    c = CASES["cfg2_bicubic"]
+    s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    t = s.device_tables()
+    u = torch.as_tensor(c.points[0], device="cuda")
+    v = torch.as_tensor(c.points[1], device="cuda")
+    out = torch.empty((3, u.numel()), dtype=torch.float64, device="cuda")
+    jac = torch.empty((3, 2, u.numel()), dtype=torch.float64, device="cuda")
+    t.evaluate_device([u, v], out=out, check=False)            # warm-up outside the capture
+    t.jacobian_device([u, v], out=jac, check=False)
+    torch.cuda.synchronize()
+    expect, expect_j = out.clone(), jac.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        t.evaluate_device([u, v], out=out, check=False)
+        t.jacobian_device([u, v], out=jac, check=False)
+    out.zero_(); jac.zero_()
+    u.copy_(torch.as_tensor(c.points[0][::-1].copy(), device="cuda"))      # new inputs, same buffers
+    v.copy_(torch.as_tensor(c.points[1][::-1].copy(), device="cuda"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, expect.flip(1)) and torch.equal(jac, expect_j.flip(2))
+    t.domain_status()
