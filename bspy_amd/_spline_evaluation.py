@@ -165,6 +165,40 @@ def normal(self, uvw, normalize=True, indices=None):
     return out if indices is None else out[list(indices)]
 
 
+def curvature(self, uv):
+    """Reference bspy/_spline_evaluation.py:80-107: curvature of a curve (nDep >= 2; signed in
+    2-D) or Gaussian curvature of a surface in 3-D, at one point or (extension) at arrays of
+    points.  The reference's nDep == 1 branch (graph of a function) is not covered."""
+    if not ((self.nInd == 1 and self.nDep >= 2) or (self.nInd == 2 and self.nDep == 3)):
+        raise NotImplementedError("curvature needs a curve with nDep >= 2 or a surface with nDep == 3")
+    if self.nInd == 1 and (np.isscalar(uv) or np.ndim(uv) == 0):
+        uv = [uv]
+    batched = len(uv) == self.nInd and not np.isscalar(uv[0]) and \
+        (uv[0].ndim if hasattr(uv[0], "ndim") else np.ndim(uv[0])) > 0
+    if batched:
+        if any(_is_torch(a) for a in uv):
+            import torch
+            dev = next(a for a in uv if _is_torch(a) and a.is_cuda).device
+            ts = torch.broadcast_tensors(*[(a if _is_torch(a) else torch.as_tensor(np.asarray(a))).to(dev) for a in uv])
+            return device_tables(self, dev.index).curvature_device(ts).view(tuple(ts[0].shape))
+        arrays = [np.asarray(a) for a in uv]
+        shape = np.broadcast_shapes(*[a.shape for a in arrays])
+        flat = [np.ascontiguousarray(np.broadcast_to(a, shape), compute_dtype(self)).reshape(-1) for a in arrays]
+        try:
+            out = device_tables(self).curvature(flat)
+        except nv.DomainError as e:
+            raise ValueError(_domain_message(arrays, shape, e.index)) from None
+        return out.reshape(shape)
+    uv = np.atleast_1d(uv)
+    if len(uv) != self.nInd:
+        raise ValueError(f"Incorrect number of parameter values: {len(uv)}")
+    try:
+        out = device_tables(self).curvature([uv[i:i + 1] for i in range(self.nInd)])
+    except nv.DomainError:
+        raise ValueError(f"Spline evaluation outside domain: {uv}") from None
+    return out[0]
+
+
 # --------------------------------------------------------------------------------------
 # batched entry points
 # --------------------------------------------------------------------------------------

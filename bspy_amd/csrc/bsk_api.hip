@@ -1016,6 +1016,105 @@ extern "C" bsk_status bsk_normal(bsk_spline s, const void *const *uvw, int64_t n
 }
 
 // ------------------------------------------------------------------------------------
+// curvature
+// ------------------------------------------------------------------------------------
+template <typename T>
+static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long n, bsk_mem mem, void *out, hipStream_t st,
+                                int64_t *first_bad)
+{
+    if (first_bad) *first_bad = -1;
+    if (n == 0) return BSK_OK;
+    const bool surface = s->nInd == 2;
+    const int nbuf = surface ? 6 : 2;                    // derivative buffers (+ normal) of nDep rows each
+    const long long chunk = std::min<long long>(n, mem == BSK_HOST ? HOST_CHUNK : (1ll << 22));
+    DevBuf work;                                         // derivative workspace (freed on return)
+    HIPCHK(work.reserve(sizeof(T) * (size_t)chunk * s->nDep * nbuf));
+    struct Guard { DevBuf &b; ~Guard() { b.release(); } } guard{work};
+    T *w = static_cast<T *>(work.p);
+    T *din = nullptr, *dout = static_cast<T *>(out);
+    if (mem == BSK_HOST) {
+        HIPCHK(s->in_ws.reserve(sizeof(T) * (size_t)chunk * s->nInd));
+        HIPCHK(s->out_ws.reserve(sizeof(T) * (size_t)chunk));
+        din = static_cast<T *>(s->in_ws.p);
+    }
+    const size_t one = (size_t)chunk * s->nDep;
+    for (long long start = 0; start < n; start += chunk) {
+        const long long m = std::min(chunk, n - start);
+        Params<T> prm;
+        for (int iv = 0; iv < MAXI; ++iv) prm.p[iv] = nullptr;
+        for (int iv = 0; iv < s->nInd; ++iv) {
+            if (mem == BSK_HOST) {
+                HIPCHK(hipMemcpyAsync(din + (size_t)iv * m, static_cast<const T *>(uvw[iv]) + start, sizeof(T) * (size_t)m,
+                                      hipMemcpyHostToDevice, st));
+                prm.p[iv] = din + (size_t)iv * m;
+            } else {
+                prm.p[iv] = static_cast<const T *>(uvw[iv]) + start;
+            }
+        }
+        T *o = mem == BSK_HOST ? static_cast<T *>(s->out_ws.p) : dout + start;
+        auto deriv = [&](int w0, int w1, T *dst) -> bsk_status {
+            Wrt wr;
+            for (int iv = 0; iv < MAXI; ++iv) wr.w[iv] = 0;
+            wr.w[0] = w0;
+            wr.w[1] = w1;
+            return dispatch_eval<T>(s, prm, m, dst, m, wr, st);
+        };
+        const int block = 256;
+        const int grid = (int)std::max<long long>(1, std::min<long long>((m + block - 1) / block, (long long)s->num_cu * 8));
+        bsk_status r;
+        if (!surface) {
+            if ((r = deriv(1, 0, w)) != BSK_OK) return r;
+            if ((r = deriv(2, 0, w + one)) != BSK_OK) return r;
+            hipLaunchKernelGGL((curvature_curve<T>), dim3(grid), dim3(block), 0, st, w, w + one, s->nDep, m, o);
+        } else {
+            if ((r = deriv(1, 0, w)) != BSK_OK) return r;
+            if ((r = deriv(0, 1, w + one)) != BSK_OK) return r;
+            if ((r = deriv(2, 0, w + 2 * one)) != BSK_OK) return r;
+            if ((r = deriv(1, 1, w + 3 * one)) != BSK_OK) return r;
+            if ((r = deriv(0, 2, w + 4 * one)) != BSK_OK) return r;
+            // unit normal (fused into the jacobian kernel when the image fits LDS)
+            if (rowrot_applies<T>(s)) {
+                if ((r = launch_jac_rowrot<T, true>(s, prm, m, w + 5 * one, 1, 0, st)) != BSK_OK) return r;
+            } else {
+                HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)m * s->nDep * s->nInd));
+                T *djac = static_cast<T *>(s->aux_ws.p);
+                if ((r = dispatch_jac<T>(s, prm, m, djac, st)) != BSK_OK) return r;
+                hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(block), 0, st, djac, 2, 3, m, 1, 0, w + 5 * one);
+            }
+            hipLaunchKernelGGL((curvature_surface<T>), dim3(grid), dim3(block), 0, st, w, w + one, w + 2 * one, w + 3 * one,
+                               w + 4 * one, w + 5 * one, m, o);
+        }
+        HIPCHK(hipGetLastError());
+        if (mem == BSK_HOST) {
+            HIPCHK(hipMemcpyAsync(static_cast<T *>(out) + start, o, sizeof(T) * (size_t)m, hipMemcpyDeviceToHost, st));
+            int64_t bad = -1;
+            r = read_bad(s, st, &bad);
+            if (r == BSK_ERR_DOMAIN) {
+                if (first_bad) *first_bad = start + bad;
+                return r;
+            }
+            if (r != BSK_OK) return r;
+        }
+    }
+    // the workspace is released when this function returns: its kernels must have finished
+    HIPCHK(hipStreamSynchronize(st));
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_curvature(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem mem, void *out, void *stream,
+                                    int64_t *first_bad)
+{
+    bsk_status r = check_call(s, uvw, n, out);
+    if (r != BSK_OK) return r;
+    if (!((s->nInd == 1 && s->nDep >= 2) || (s->nInd == 2 && s->nDep == 3)))
+        return fail(BSK_ERR_UNSUPPORTED, "curvature needs a curve with nDep >= 2 or a surface with nDep == 3");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32 ? run_curvature<float>(s, uvw, n, mem, out, st, first_bad)
+                               : run_curvature<double>(s, uvw, n, mem, out, st, first_bad);
+}
+
+// ------------------------------------------------------------------------------------
 // tensor-product grid
 // ------------------------------------------------------------------------------------
 template <typename T>

@@ -518,4 +518,51 @@ __global__ __launch_bounds__(256) void normal_epilogue(const T *__restrict__ jac
     }
 }
 
+// ---------------------------------------------------------------------------------
+// curvature epilogues (next row: reference bspy/_spline_evaluation.py:80-107) on derivative
+// buffers produced by the evaluation kernels (each (nDep, N), SoA).
+// ---------------------------------------------------------------------------------
+// curves: fp = first, fpp = second derivative; signed in 2-D, unsigned otherwise
+template <typename T>
+__global__ __launch_bounds__(256) void curvature_curve(const T *__restrict__ fp, const T *__restrict__ fpp, int nDep,
+                                                       long long N, T *__restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T fpfp = T(0), fpfpp = T(0), fppfpp = T(0);
+        for (int d = 0; d < nDep; ++d) {
+            const T a = fp[(long long)d * N + n], b = fpp[(long long)d * N + n];
+            fpfp += a * a;
+            fpfpp += a * b;
+            fppfpp += b * b;
+        }
+        const T denom = fpfp * sqrt(fpfp);                       // fpDotFp ** 1.5
+        T num;
+        if (nDep == 2) num = fp[n] * fpp[N + n] - fp[N + n] * fpp[n];
+        else num = sqrt(fppfpp * fpfp - fpfpp * fpfpp);
+        out[n] = num / denom;
+    }
+}
+
+// surfaces in 3-D: Gaussian curvature from su, sv, suu, suv, svv and the unit normal
+template <typename T>
+__global__ __launch_bounds__(256) void curvature_surface(const T *__restrict__ su, const T *__restrict__ sv,
+                                                         const T *__restrict__ suu, const T *__restrict__ suv,
+                                                         const T *__restrict__ svv, const T *__restrict__ nrm,
+                                                         long long N, T *__restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T E = T(0), F = T(0), G = T(0), L = T(0), M = T(0), Nn = T(0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const long long k = (long long)d * N + n;
+            const T a = su[k], b = sv[k], c = nrm[k];
+            E += a * a; F += a * b; G += b * b;
+            L += suu[k] * c; M += suv[k] * c; Nn += svv[k] * c;
+        }
+        out[n] = (L * Nn - M * M) / (E * G - F * F);
+    }
+}
+
 }  // namespace bsk

@@ -152,6 +152,29 @@ class DeviceSpline:
             self.domain_status()
         return out
 
+    def curvature(self, points):
+        """points: nInd arrays of N values -> ndarray (N,): curvature of a curve (nDep >= 2) or
+        Gaussian curvature of a surface in 3-D."""
+        ps, n = self._host_params(points)
+        out = np.empty(n, self.dtype)
+        bad = ctypes.c_int64(-1)
+        st = nv.lib().bsk_curvature(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
+                                    out.ctypes.data, None, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
+    def curvature_device(self, points, out=None, check=True):
+        """points: nInd CUDA tensors -> CUDA tensor (N,)."""
+        torch, tdt, ps, n = self._torch_params(points)
+        if out is None:
+            out = torch.empty((n,), dtype=tdt, device=ps[0].device)
+        st = nv.lib().bsk_curvature(self._handle, nv.ptr_array([p.data_ptr() for p in ps]), n, nv.BSK_DEVICE,
+                                    out.data_ptr(), self._stream_ptr(torch, self.device), None)
+        nv.check(st)
+        if check:
+            self.domain_status()
+        return out
+
     def evaluate_grid(self, axes, wrt=None):
         """axes: nInd 1-D arrays (n_i values) -> ndarray (nDep, n_0, ..., n_{nInd-1})."""
         if len(axes) != self.nInd:

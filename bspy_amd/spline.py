@@ -144,6 +144,12 @@ class Spline:
         flips it.  Extension: nInd arrays of points -> (len(normal), *shape)."""
         return _ev.normal(self, uvw, normalize, indices)
 
+    def curvature(self, uv):
+        """Curvature of a curve (nDep >= 2) or Gaussian curvature of a surface in 3-D
+        (reference spline.py `curvature` -> _spline_evaluation.py:80-107); arrays of points
+        give an array of curvatures."""
+        return _ev.curvature(self, uv)
+
     def tangent_space(self, uvw):
         """Same as jacobian (reference spline.py:2238-2252)."""
         return _ev.jacobian(self, uvw)

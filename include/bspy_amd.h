@@ -112,6 +112,16 @@ bsk_status bsk_normal(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem m
                       void *out, void *stream, int64_t *first_bad);
 
 /*
+ * Batched curvature (next row).
+ * Replaces: Spline.curvature, bspy/_spline_evaluation.py:80-107 (single point there).
+ *   curves (nInd 1, nDep >= 2): signed curvature in 2-D, unsigned otherwise;
+ *   surfaces in 3-D (nInd 2, nDep 3): Gaussian curvature.
+ *   out : n values
+ */
+bsk_status bsk_curvature(bsk_spline s, const void *const *uvw, int64_t n, bsk_mem mem, void *out, void *stream,
+                         int64_t *first_bad);
+
+/*
  * Tensor-product grid evaluation: parameters are the outer product of per-variable
  * vectors (the reference's broadcast call s(u[:, None], v[None, :]), bspy/spline.py:941-945).
  *   grid[iv]   : ngrid[iv] values of variable iv

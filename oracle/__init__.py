@@ -49,6 +49,7 @@ def _lib():
             getattr(_LIB, "orc_evaluate_" + suf).restype = ctypes.c_long
             getattr(_LIB, "orc_jacobian_" + suf).restype = ctypes.c_long
             getattr(_LIB, "orc_normal_" + suf).restype = ctypes.c_long
+            getattr(_LIB, "orc_curvature_" + suf).restype = ctypes.c_long
     return _LIB
 
 
@@ -233,3 +234,15 @@ def py_normal(order, nCoef, knots, coefs, uvw, normalize=True, negate=False, ind
     if normalize:
         normal /= np.linalg.norm(normal)
     return normal
+
+
+def c_curvature(order, nCoef, knots, coefs, points):
+    """Batched curvature (bspy/_spline_evaluation.py:80-107): curves with nDep >= 2 and
+    surfaces in 3-D.  Returns (out (N,), first_bad_index or -1)."""
+    dt, suf, ct, ks, cf, ps, kp, pp, o, c, IntArr = _prep(order, nCoef, knots, coefs, points)
+    n = len(ps[0]) if ps else 1
+    out = np.zeros(n, dt)
+    bad = getattr(_lib(), "orc_curvature_" + suf)(
+        ctypes.c_int(len(order)), ctypes.c_int(cf.shape[0]), o, c, kp, cf.ctypes.data_as(ctypes.POINTER(ct)),
+        pp, ctypes.c_long(n), out.ctypes.data_as(ctypes.POINTER(ct)))
+    return out, int(bad)

@@ -219,6 +219,56 @@ long FN(orc_normal)(int nInd, int nDep, const int *order, const int *nCoef, cons
     return bad;
 }
 
+/* Batched curvature (bspy/_spline_evaluation.py:80-107): curves (nInd 1, nDep >= 2: signed in
+ * 2-D, unsigned otherwise) and surfaces in 3-D (nInd 2, nDep 3: Gaussian curvature).  out[n]. */
+long FN(orc_curvature)(int nInd, int nDep, const int *order, const int *nCoef, const REAL *const *knots,
+                       const REAL *coefs, const REAL *const *uvw, long N, REAL *out)
+{
+    long win = nDep;
+    for (int iv = 0; iv < nInd; ++iv) win *= order[iv];
+    REAL *work = (REAL *)malloc(sizeof(REAL) * (size_t)(win > 0 ? win : 1));
+    REAL p[ORC_MAX_NIND];
+    long bad = -1;
+    for (long n = 0; n < N; ++n) {
+        for (int iv = 0; iv < nInd; ++iv) {
+            p[iv] = uvw[iv][n];
+            if (p[iv] < knots[iv][order[iv] - 1] || p[iv] > knots[iv][nCoef[iv]]) bad = n;
+        }
+        if (bad >= 0) break;
+        if (nInd == 1) {                                                            /* :83-93 */
+            REAL fp[ORC_MAX_NDEP], fpp[ORC_MAX_NDEP];
+            int w1[1] = {1}, w2[1] = {2};
+            FN(orc_point)(1, nDep, order, nCoef, knots, coefs, w1, p, work, fp);
+            FN(orc_point)(1, nDep, order, nCoef, knots, coefs, w2, p, work, fpp);
+            REAL fpfp = 0, fpfpp = 0, fppfpp = 0;
+            for (int d = 0; d < nDep; ++d) { fpfp += fp[d] * fp[d]; fpfpp += fp[d] * fpp[d]; fppfpp += fpp[d] * fpp[d]; }
+            const REAL denom = (REAL)pow((double)fpfp, 1.5);
+            REAL num;
+            if (nDep == 2) num = fp[0] * fpp[1] - fp[1] * fpp[0];
+            else num = (REAL)sqrt((double)(fppfpp * fpfp - fpfpp * fpfpp));
+            out[n] = num / denom;
+        } else {                                                                    /* :94-107 */
+            REAL su[3], sv[3], suu[3], suv[3], svv[3], nrm[3];
+            int w10[2] = {1, 0}, w01[2] = {0, 1}, w20[2] = {2, 0}, w11[2] = {1, 1}, w02[2] = {0, 2};
+            FN(orc_point)(2, 3, order, nCoef, knots, coefs, w10, p, work, su);
+            FN(orc_point)(2, 3, order, nCoef, knots, coefs, w01, p, work, sv);
+            FN(orc_point)(2, 3, order, nCoef, knots, coefs, w20, p, work, suu);
+            FN(orc_point)(2, 3, order, nCoef, knots, coefs, w11, p, work, suv);
+            FN(orc_point)(2, 3, order, nCoef, knots, coefs, w02, p, work, svv);
+            const REAL *pt[2] = {&p[0], &p[1]};
+            FN(orc_normal)(2, 3, order, nCoef, knots, coefs, pt, 1, 1, 0, nrm);
+            REAL E = 0, F = 0, G = 0, L = 0, M = 0, Nn = 0;
+            for (int d = 0; d < 3; ++d) {
+                E += su[d] * su[d]; F += su[d] * sv[d]; G += sv[d] * sv[d];
+                L += suu[d] * nrm[d]; M += suv[d] * nrm[d]; Nn += svv[d] * nrm[d];
+            }
+            out[n] = (L * Nn - M * M) / (E * G - F * F);
+        }
+    }
+    free(work);
+    return bad;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -123,6 +123,11 @@ def run_case(bspy, c):
             na[i] = s.normal(uvw, False)
             nf[i] = flipped.normal(uvw, False)
         out["normal_unit"], out["normal_area"], out["normal_area_negated"] = nu, na, nf
+    if (c.nInd == 1 and c.nDep >= 2) or (c.nInd == 2 and c.nDep == 3):
+        # Spline.curvature (bspy/_spline_evaluation.py:80-107), first 128 points
+        m = min(c.n, 128)
+        with np.errstate(all="ignore"):
+            out["curvature"] = np.array([s.curvature([p[i] for p in c.points]) for i in range(m)], np.float64)
     return out
 
 

@@ -487,3 +487,36 @@ def test_hip_graph_capture_of_device_calls():
     torch.cuda.synchronize()
     assert torch.equal(out, expect.flip(1)) and torch.equal(jac, expect_j.flip(2))
     t.domain_status()
+
+
+CURVATURE_CASES = [n for n, c in CASES.items() if (c.nInd == 1 and c.nDep >= 2) or (c.nInd == 2 and c.nDep == 3)]
+
+
+@pytest.mark.parametrize("name", sorted(CURVATURE_CASES))
+def test_curvature_against_reference(name, golden_parity):
+    """Batched Spline.curvature against the reference's single-point curvature."""
+    c = CASES[name]
+    ref = golden_parity[f"{name}/curvature"]
+    pts = [p[:len(ref)] for p in c.points]
+    s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
+    out = np.asarray(s.curvature(pts), np.float64)
+    assert out.shape == ref.shape
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    ok = np.isfinite(ref)
+    f32 = c.knots[0].dtype == np.float32 or c.coefs.dtype == np.float32
+    if ok.any():
+        err = np.abs(out[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok]))
+        assert err.max() <= (2e-3 if f32 else 1e-8), (name, err.max())
+        orc, _ = oracle.c_curvature(c.order, c.nCoef, c.knots, c.coefs, pts)
+        err = np.abs(out[ok] - orc[ok]) / np.maximum(1.0, np.abs(orc[ok]))
+        assert err.max() <= (2e-3 if f32 else 1e-8)
+        one = s.curvature([float(p[5]) for p in c.points])            # single point
+        assert abs(one - ref[5]) <= (2e-3 if f32 else 1e-8) * max(1.0, abs(ref[5]))
+
+
+def test_reference_curvature_pin(golden_tables):
+    """reference test_curvature: Gaussian curvature of mySurface at (0.25, 0.5) is 1.024
+    (tests/bspy_test.py:699-700)."""
+    t = golden_tables
+    surf = Spline(2, 3, [3, 4], [4, 5], [t["surface_knots0"], t["surface_knots1"]], t["surface_coefs"])
+    assert abs(surf.curvature([0.25, 0.5]) - 1.024) < 1e-13

@@ -158,3 +158,29 @@ def test_normal_oracle_against_reference(name, golden_parity):
     if c.coefs.dtype == np.float64 and c.order[0] > 1:
         r = oracle.py_normal(c.order, c.nCoef, c.knots, c.coefs, [float(p[3]) for p in c.points])
         assert np.abs(r - golden_parity[f"{name}/normal_unit"][3]).max() <= 1e-12
+
+
+CURVATURE_CASES = [n for n, c in CASES.items() if (c.nInd == 1 and c.nDep >= 2) or (c.nInd == 2 and c.nDep == 3)]
+
+
+def _curv_tol(c):
+    if c.knots[0].dtype == np.float32 or c.coefs.dtype == np.float32:
+        return 2e-3          # second derivatives in fp32
+    return 1e-9
+
+
+@pytest.mark.parametrize("name", sorted(CURVATURE_CASES))
+def test_curvature_oracle_against_reference(name, golden_parity):
+    """Oracle curvature (next row 8f-1) against Spline.curvature of the reference."""
+    c = CASES[name]
+    ref = golden_parity[f"{name}/curvature"]
+    pts = [p[:len(ref)] for p in c.points]
+    with np.errstate(all="ignore"):
+        out, bad = oracle.c_curvature(c.order, c.nCoef, c.knots, c.coefs, pts)
+    assert bad == -1
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    if ok.any():
+        # relative to each value's own size: curvatures span many orders of magnitude
+        err = np.abs(out[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok]))
+        assert err.max() <= _curv_tol(c), (name, err.max())
