@@ -22,6 +22,33 @@
 
 namespace bsk {
 
+// Copy the table image into LDS with several global loads in flight per lane (the plain
+// `s[i] = g[i]` loop compiles to load - wait - write, one L2 round trip per element: ~13 round
+// trips for the 104 KB image).  Coefficient rows get the odd stride rs.
+template <typename T>
+__device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d, const TileDesc<T> &td,
+                                                   const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                   const T *__restrict__ gcoef, int nc1, int rs)
+{
+    T *stab = reinterpret_cast<T *>(smem);
+    unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
+    T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
+    constexpr int U = 8;
+    const int bd = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < d.coef_len; i0 += bd * U) {
+        T v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const int i = i0 + k * bd; v[k] = i < d.coef_len ? gcoef[i] : T(0); }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = i0 + k * bd;
+            if (i < d.coef_len) { const int row = i / nc1, col = i - row * nc1; scoef[row * rs + col] = v[k]; }
+        }
+    }
+    for (int i = threadIdx.x; i < d.tab_len; i += bd) stab[i] = gtab[i];
+    for (int i = threadIdx.x; i < td.lut_len; i += bd) slut[i] = glut[i];
+}
+
 template <typename T, int O, bool DERIV>
 __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                     const T *__restrict__ gtab, const unsigned *__restrict__ glut,
@@ -38,17 +65,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     const int rs = nc1 | 1;                                   // odd LDS row stride (elements)
     const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
     const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
-    {
-        T *stab = reinterpret_cast<T *>(smem);
-        unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
-        T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
-        for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
-        for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
-        for (int i = threadIdx.x; i < d.coef_len; i += blockDim.x) {
-            const int row = i / nc1, col = i - row * nc1;     // row = dep * nc0 + i0
-            scoef[row * rs + col] = gcoef[i];
-        }
-    }
+    stage_image_rowrot<T>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
     // per-wave class counters of the rank rotation: [wave][half-wave][class]
     unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes +
@@ -133,17 +150,7 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
     const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
     const int rs = nc1 | 1;
     const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
-    {
-        T *stab = reinterpret_cast<T *>(smem);
-        unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
-        T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
-        for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
-        for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
-        for (int i = threadIdx.x; i < d.coef_len; i += blockDim.x) {
-            const int row = i / nc1, col = i - row * nc1;
-            scoef[row * rs + col] = gcoef[i];
-        }
-    }
+    stage_image_rowrot<T>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
     unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes +
                                                  (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
