@@ -11,7 +11,6 @@
 #include "bsk_kernels.hpp"
 #include "bsk_tile.hpp"
 #include "bsk_stream.hpp"
-#include "bsk_surface.hpp"
 #include "bsk_rowrot.hpp"
 #include "bsk_gather.hpp"
 
@@ -74,8 +73,7 @@ struct bsk_spline_s {
     void *coef = nullptr;    // device coefficients
     void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
     unsigned *lut = nullptr; // device span-search bucket tables
-    int dbg = 0;             // BSK_DEBUG: timing-only ablation bits of eval_perm (results wrong)
-    int variant = 0;         // BSK_VARIANT override: 0 auto (= 4), 1 simple, 2 tile, 3 tile + bank permutation, 4 stream, 5 perm (pipelined bank permutation), 6 surface2 (two points per lane)
+    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -315,7 +313,6 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
     HIPCHK_C(hipMalloc((void **)&s->lut, std::max<size_t>(16, sizeof(unsigned) * (size_t)(dtype == BSK_F32 ? s->t32.lut_len : s->t64.lut_len))));
     HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
     if (const char *v = getenv("BSK_VARIANT")) s->variant = atoi(v);
-    if (const char *v = getenv("BSK_DEBUG")) s->dbg = atoi(v);
     HIPCHK_C(hipMemset(s->bad, 0xff, sizeof(unsigned long long)));
 #undef HIPCHK_C
     st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
@@ -452,82 +449,77 @@ static bsk_status launch_eval_generic(bsk_spline s, const Params<T> &prm, long l
     return BSK_OK;
 }
 
-// Tile kernels (bsk_tile.hpp): whole table image in LDS.  Returns the LDS bytes needed, or 0
-// when the image (plus, for perm, the staging area) does not fit.
+// LDS-resident kernels: bytes of the table image (axis tables, bucket tables, coefficients),
+// or 0 when it does not fit in one CU's LDS.
 template <typename T>
-static size_t tile_lds_bytes(bsk_spline s, bool perm)
+static size_t tile_lds_bytes(bsk_spline s, bool /*unused*/)
 {
     const TileDesc<T> &td = tile_of<T>(s);
-    size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes + TILE * sizeof(unsigned);   // + rank-rotation counters
-    if (perm)
-        b += (size_t)s->nInd * TILE * sizeof(T) + (size_t)s->nInd * TILE * 2 + 2 * TILE * 2 +
-             (NCLASS + 2 * (NCLASS + 1) + 2) * sizeof(int) + (size_t)s->nDep * TILE * sizeof(T);
+    const size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes;
     for (int iv = 0; iv < s->nInd; ++iv)
         if (s->ncoef[iv] > 65535) return 0;
     return b <= s->lds_max ? b : 0;
 }
 
-// eval_perm staging: parameters, packed spans, slot and overflow lists, class counters, all
-// double buffered by tile parity.  Needs every nCoef <= 1023 (10-bit packed spans).
+static bool has_fixed_path(bsk_spline s);
+
+// eval_rowrot / jac_rowrot / fused normal: surfaces of order 2 or 4 whose odd-stride image fits LDS
 template <typename T>
-static size_t perm_lds_bytes(bsk_spline s)
+static size_t rowrot_lds_bytes(bsk_spline s)
 {
-    const TileDesc<T> &td = tile_of<T>(s);
-    for (int iv = 0; iv < s->nInd; ++iv)
-        if (s->ncoef[iv] > 1023) return 0;
-    if (s->nInd > 3) return 0;
-    const size_t b = (size_t)td.tab_bytes + td.lut_bytes + td.coef_bytes + 2 * (size_t)s->nInd * TILE * sizeof(T) +
-                     2 * TILE * sizeof(unsigned) + 4 * TILE * sizeof(unsigned short) + 2 * NCLASS * sizeof(int);
-    return b <= s->lds_max ? b : 0;
+    const TileDesc<T> &tdr = tile_of<T>(s);
+    const size_t rs = (size_t)(s->ncoef[1] | 1);
+    const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
+    return (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
 }
 
-template <typename T, int NIND, int O>
-static bsk_status launch_eval_perm(bsk_spline s, size_t lds, const Params<T> &prm, long long n, T *out,
-                                   long long ostride, const Wrt &w, hipStream_t st)
+template <typename T>
+static bool rowrot_applies(bsk_spline s)
+{
+    return has_fixed_path(s) && s->nInd == 2 && (s->order[0] == 2 || s->order[0] == 4) &&
+           (s->variant == 0 || s->variant == 9) && rowrot_lds_bytes<T>(s) <= s->lds_max;
+}
+
+template <typename T, bool NORMAL>
+static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long long n, T *out, int normalize, int negate,
+                                    hipStream_t st)
 {
     const Desc<T> &d = desc_of<T>(s);
-    const TileDesc<T> &td = tile_of<T>(s);
+    const TileDesc<T> &tdr = tile_of<T>(s);
+    const size_t lds_rr = rowrot_lds_bytes<T>(s);
+    const long long nt = (n + TILE - 1) / TILE;
+    const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
     const T *tab = static_cast<const T *>(s->tab);
     const T *coef = static_cast<const T *>(s->coef);
-    const long long ntiles = (n + TILE - 1) / TILE;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu));
-    bool deriv = false;
-    for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
-    if (deriv) {
-        HIPCHK(allow_lds(eval_perm<T, NIND, O, true>, lds));
-        hipLaunchKernelGGL((eval_perm<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad, s->dbg);
+    if (s->order[0] == 4) {
+        HIPCHK(allow_lds(jac_rowrot<T, 4, NORMAL>, lds_rr));
+        hipLaunchKernelGGL((jac_rowrot<T, 4, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
+                           s->bad, normalize, negate);
     } else {
-        HIPCHK(allow_lds(eval_perm<T, NIND, O, false>, lds));
-        hipLaunchKernelGGL((eval_perm<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad, s->dbg);
+        HIPCHK(allow_lds(jac_rowrot<T, 2, NORMAL>, lds_rr));
+        hipLaunchKernelGGL((jac_rowrot<T, 2, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
+                           s->bad, normalize, negate);
     }
     HIPCHK(hipGetLastError());
     return BSK_OK;
 }
 
 template <typename T, int NIND, int O>
-static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Params<T> &prm, long long n, T *out,
-                                   long long ostride, const Wrt &w, hipStream_t st)
+static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm, long long n, T *out, long long ostride,
+                                  const Wrt &w, hipStream_t st)
 {
     const Desc<T> &d = desc_of<T>(s);
     const TileDesc<T> &td = tile_of<T>(s);
     const T *tab = static_cast<const T *>(s->tab);
     const T *coef = static_cast<const T *>(s->coef);
-    const long long ntiles = (n + TILE - 1) / TILE;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
-    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     bool deriv = false;
     for (int iv = 0; iv < s->nInd; ++iv) deriv |= w.w[iv] != 0;
+    const long long ntiles = (n + TILE - 1) / TILE;
     if constexpr (NIND == 2 && (O == 2 || O == 4)) {
-        // default surface kernel: row rotation on an odd-stride LDS image
-        const TileDesc<T> &tdr = tile_of<T>(s);
-        const size_t rs = (size_t)(s->ncoef[1] | 1);
-        const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
-        const size_t lds_rr = (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
-        if ((s->variant == 0 || s->variant == 9) && lds_rr <= s->lds_max) {
-            const long long nt = (n + TILE - 1) / TILE;
-            const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
+        // surfaces of order 2 / 4: row rotation on an odd-stride LDS image
+        if (rowrot_applies<T>(s)) {
+            const size_t lds_rr = rowrot_lds_bytes<T>(s);
+            const int g = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
             if (deriv) {
                 HIPCHK(allow_lds(eval_rowrot<T, O, true>, lds_rr));
                 hipLaunchKernelGGL((eval_rowrot<T, O, true>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, prm, n,
@@ -541,78 +533,15 @@ static bsk_status launch_eval_tile(bsk_spline s, bool perm, size_t lds, const Pa
             return BSK_OK;
         }
     }
-    if constexpr (NIND == 2) {
-        // plain-C++ surface kernel, one (variant 7) or two (variant 8) points per lane
-        const bool aligned2 = (((uintptr_t)prm.p[0] | (uintptr_t)prm.p[1] | (uintptr_t)out) & 15) == 0 &&
-                              (ostride * (long long)sizeof(T)) % 16 == 0;
-        if (s->variant == 7 || (s->variant == 8 && !aligned2)) {
-            const long long nt1 = (n + 1023) / 1024;
-            const int g1 = (int)std::max<long long>(1, std::min<long long>(nt1, (long long)s->num_cu * per_cu));
-            if (deriv) {
-                HIPCHK(allow_lds(eval_surface<T, O, true, 1>, lds));
-                hipLaunchKernelGGL((eval_surface<T, O, true, 1>), dim3(g1), dim3(1024), lds, st, d, td, tab, s->lut, coef,
-                                   prm, n, out, ostride, w, s->bad);
-            } else {
-                HIPCHK(allow_lds(eval_surface<T, O, false, 1>, lds));
-                hipLaunchKernelGGL((eval_surface<T, O, false, 1>), dim3(g1), dim3(1024), lds, st, d, td, tab, s->lut, coef,
-                                   prm, n, out, ostride, w, s->bad);
-            }
-            HIPCHK(hipGetLastError());
-            return BSK_OK;
-        }
-        if (s->variant == 8) {
-            const long long nt2 = ((n + 1) / 2 + 511) / 512;
-            const int g2 = (int)std::max<long long>(1, std::min<long long>(nt2, (long long)s->num_cu * per_cu));
-            if (deriv) {
-                HIPCHK(allow_lds(eval_surface<T, O, true, 2>, lds));
-                hipLaunchKernelGGL((eval_surface<T, O, true, 2>), dim3(g2), dim3(512), lds, st, d, td, tab, s->lut, coef,
-                                   prm, n, out, ostride, w, s->bad);
-            } else {
-                HIPCHK(allow_lds(eval_surface<T, O, false, 2>, lds));
-                hipLaunchKernelGGL((eval_surface<T, O, false, 2>), dim3(g2), dim3(512), lds, st, d, td, tab, s->lut, coef,
-                                   prm, n, out, ostride, w, s->bad);
-            }
-            HIPCHK(hipGetLastError());
-            return BSK_OK;
-        }
-    }
-    if constexpr (NIND == 2 && (O == 2 || O == 4)) {
-        // two adjacent points per lane with 16-byte loads/stores: needs aligned rows
-        const bool aligned = (((uintptr_t)prm.p[0] | (uintptr_t)prm.p[1] | (uintptr_t)out) & 15) == 0 &&
-                             (ostride * (long long)sizeof(T)) % 16 == 0;
-        if (s->variant == 6 && aligned) {
-            constexpr int DEPTH = 4;
-            const long long npairs = (n + 1) / 2;
-            const long long nt2 = (npairs + SURF2_BLOCK - 1) / SURF2_BLOCK;
-            const int grid2 = (int)std::max<long long>(1, std::min<long long>(nt2, (long long)s->num_cu * per_cu));
-            if (deriv) {
-                HIPCHK(allow_lds(eval_surface2<T, O, true, DEPTH>, lds));
-                hipLaunchKernelGGL((eval_surface2<T, O, true, DEPTH>), dim3(grid2), dim3(SURF2_BLOCK), lds, st, d, td, tab,
-                                   s->lut, coef, prm, n, out, ostride, w, s->bad);
-            } else {
-                HIPCHK(allow_lds(eval_surface2<T, O, false, DEPTH>, lds));
-                hipLaunchKernelGGL((eval_surface2<T, O, false, DEPTH>), dim3(grid2), dim3(SURF2_BLOCK), lds, st, d, td, tab,
-                                   s->lut, coef, prm, n, out, ostride, w, s->bad);
-            }
-            HIPCHK(hipGetLastError());
-            return BSK_OK;
-        }
-    }
-    if ((s->variant == 0 || s->variant == 4) && deriv) {
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
+    const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
+    if (deriv) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, true>, lds));
         hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad, s->dbg);
-    } else if (s->variant == 0 || s->variant == 4) {
-        HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
-        hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
-                           n, out, ostride, w, s->bad, s->dbg);
-    } else if (perm) {
-        HIPCHK(allow_lds(eval_tile<T, NIND, O, true>, lds));
-        hipLaunchKernelGGL((eval_tile<T, NIND, O, true>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     } else {
-        HIPCHK(allow_lds(eval_tile<T, NIND, O, false>, lds));
-        hipLaunchKernelGGL((eval_tile<T, NIND, O, false>), dim3(grid), dim3(TILE), lds, st, d, td, tab, s->lut, coef, prm,
+        HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
+        hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     }
     HIPCHK(hipGetLastError());
@@ -696,29 +625,15 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
                                 const Wrt &w, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
-    if (has_fixed_path(s) && s->order[0] <= 5 && s->variant == 5) {
-        const size_t plds = perm_lds_bytes<T>(s);
-        if (plds != 0) {
-#define CALL_PERM(NIND, O) launch_eval_perm<T, NIND, O>(s, plds, prm, n, out, ostride, w, st)
-            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_PERM) }
-            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_PERM) }
-            else { BSK_ORDER_SWITCH5(3, CALL_PERM) }
-#undef CALL_PERM
-        }
-    }
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
-        // table image fits in LDS: tile kernel; bank permutation pays once a tile is full and
-        // the window is at least a surface's
-        const bool want_perm = s->variant == 3;   // measured slower than the plain tile kernel so far (profiles/)
-        size_t lds = want_perm ? tile_lds_bytes<T>(s, true) : 0;
-        bool perm = lds != 0;
-        if (!perm) lds = tile_lds_bytes<T>(s, false);
+        // table image fits in LDS: eval_rowrot (surfaces of order 2 / 4) or eval_stream
+        const size_t lds = tile_lds_bytes<T>(s, false);
         if (lds != 0) {
-#define CALL_TILE(NIND, O) launch_eval_tile<T, NIND, O>(s, perm, lds, prm, n, out, ostride, w, st)
-            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_TILE) }
-            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_TILE) }
-            else { BSK_ORDER_SWITCH5(3, CALL_TILE) }
-#undef CALL_TILE
+#define CALL_LDS(NIND, O) launch_eval_lds<T, NIND, O>(s, lds, prm, n, out, ostride, w, st)
+            if (s->nInd == 1) { BSK_ORDER_SWITCH5(1, CALL_LDS) }
+            else if (s->nInd == 2) { BSK_ORDER_SWITCH5(2, CALL_LDS) }
+            else { BSK_ORDER_SWITCH5(3, CALL_LDS) }
+#undef CALL_LDS
         }
     }
     if (has_fixed_path(s) && s->coef_aos && s->variant != 1) {
@@ -737,47 +652,6 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
 #undef CALL_EVAL
     }
     return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
-}
-
-// jac_rowrot / fused normal: surfaces of order 2 or 4 whose odd-stride image fits LDS
-template <typename T>
-static size_t rowrot_lds_bytes(bsk_spline s)
-{
-    const TileDesc<T> &tdr = tile_of<T>(s);
-    const size_t rs = (size_t)(s->ncoef[1] | 1);
-    const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
-    return (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
-}
-
-template <typename T>
-static bool rowrot_applies(bsk_spline s)
-{
-    return has_fixed_path(s) && s->nInd == 2 && (s->order[0] == 2 || s->order[0] == 4) &&
-           (s->variant == 0 || s->variant == 9) && rowrot_lds_bytes<T>(s) <= s->lds_max;
-}
-
-template <typename T, bool NORMAL>
-static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long long n, T *out, int normalize, int negate,
-                                    hipStream_t st)
-{
-    const Desc<T> &d = desc_of<T>(s);
-    const TileDesc<T> &tdr = tile_of<T>(s);
-    const size_t lds_rr = rowrot_lds_bytes<T>(s);
-    const long long nt = (n + TILE - 1) / TILE;
-    const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
-    const T *tab = static_cast<const T *>(s->tab);
-    const T *coef = static_cast<const T *>(s->coef);
-    if (s->order[0] == 4) {
-        HIPCHK(allow_lds(jac_rowrot<T, 4, NORMAL>, lds_rr));
-        hipLaunchKernelGGL((jac_rowrot<T, 4, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
-                           s->bad, normalize, negate);
-    } else {
-        HIPCHK(allow_lds(jac_rowrot<T, 2, NORMAL>, lds_rr));
-        hipLaunchKernelGGL((jac_rowrot<T, 2, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
-                           s->bad, normalize, negate);
-    }
-    HIPCHK(hipGetLastError());
-    return BSK_OK;
 }
 
 template <typename T>

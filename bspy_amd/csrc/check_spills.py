@@ -1,4 +1,4 @@
-"""Build-time guard: the kernels that read LDS through inline asm (eval_tile, eval_stream)
+"""Build-time guard: the kernels that read LDS through inline asm (eval_stream, jac_stream, eval_rowrot, jac_rowrot)
 must not use scratch: a spilled asm destination would be stored before its data arrived.
 Usage: python check_spills.py <resource-usage log>"""
 import re
@@ -8,7 +8,7 @@ log = open(sys.argv[1]).read()
 bad = []
 for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", log, re.S):
     name, scratch = m.group(1), int(m.group(2))
-    if (any(k in name for k in ("eval_tile", "eval_stream", "eval_surface2", "jac_stream", "eval_perm", "eval_rowrot", "jac_rowrot"))) and scratch:
+    if (any(k in name for k in ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot"))) and scratch:
         bad.append((name, scratch))
 if bad:
     for name, scratch in bad:

@@ -322,10 +322,10 @@ def test_empty_and_ragged():
         assert np.abs(out - orc).max() <= 1e-12 * _scale(orc)
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "4", "5", "6", "7", "8", "9"])
+@pytest.mark.parametrize("variant", ["1", "4", "9"])
 def test_kernel_variants(variant, golden_parity, monkeypatch):
-    """BSK_VARIANT pins the kernel family (1 simple, 2 LDS tile, 3 LDS tile + bank-class
-    permutation); every family must meet the same parity bar on its own."""
+    """BSK_VARIANT pins the kernel family (1 eval_fixed, 4 eval_stream, 9 eval_rowrot where it
+    applies); every family must meet the same parity bar on its own."""
     monkeypatch.setenv("BSK_VARIANT", variant)
     for name in ("cfg1_curve", "cfg2_bicubic", "cfg2_bicubic_nonuniform", "bezier_patch_f32", "curve_order5",
                  "volume_o4_d1", "surface_o7x3_d6", "curve_f32", "curve_many_knots"):
