@@ -491,15 +491,22 @@ static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long lon
     const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
     const T *tab = static_cast<const T *>(s->tab);
     const T *coef = static_cast<const T *>(s->coef);
+#define BSK_JROT(O_, ND_)                                                                                               \
+    do {                                                                                                                 \
+        HIPCHK(allow_lds(jac_rowrot<T, O_, NORMAL, ND_>, lds_rr));                                                      \
+        hipLaunchKernelGGL((jac_rowrot<T, O_, NORMAL, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, \
+                           prm, n, out, s->bad, normalize, negate);                                                     \
+    } while (0)
+    // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
+    const int nd = (NORMAL || s->nDep > 3) ? 0 : s->nDep;
     if (s->order[0] == 4) {
-        HIPCHK(allow_lds(jac_rowrot<T, 4, NORMAL>, lds_rr));
-        hipLaunchKernelGGL((jac_rowrot<T, 4, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
-                           s->bad, normalize, negate);
+        if constexpr (NORMAL) BSK_JROT(4, 0);
+        else switch (nd) { case 1: BSK_JROT(4, 1); break; case 2: BSK_JROT(4, 2); break; case 3: BSK_JROT(4, 3); break; default: BSK_JROT(4, 0); }
     } else {
-        HIPCHK(allow_lds(jac_rowrot<T, 2, NORMAL>, lds_rr));
-        hipLaunchKernelGGL((jac_rowrot<T, 2, NORMAL>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, prm, n, out,
-                           s->bad, normalize, negate);
+        if constexpr (NORMAL) BSK_JROT(2, 0);
+        else switch (nd) { case 1: BSK_JROT(2, 1); break; case 2: BSK_JROT(2, 2); break; case 3: BSK_JROT(2, 3); break; default: BSK_JROT(2, 0); }
     }
+#undef BSK_JROT
     HIPCHK(hipGetLastError());
     return BSK_OK;
 }
@@ -520,15 +527,23 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
         if (rowrot_applies<T>(s)) {
             const size_t lds_rr = rowrot_lds_bytes<T>(s);
             const int g = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
-            if (deriv) {
-                HIPCHK(allow_lds(eval_rowrot<T, O, true>, lds_rr));
-                hipLaunchKernelGGL((eval_rowrot<T, O, true>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, prm, n,
-                                   out, ostride, w, s->bad);
-            } else {
-                HIPCHK(allow_lds(eval_rowrot<T, O, false>, lds_rr));
-                hipLaunchKernelGGL((eval_rowrot<T, O, false>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, prm, n,
-                                   out, ostride, w, s->bad);
-            }
+            // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
+#define BSK_ROWROT(DERIV_, ND_)                                                                                          \
+    do {                                                                                                                 \
+        HIPCHK(allow_lds(eval_rowrot<T, O, DERIV_, ND_>, lds_rr));                                                      \
+        hipLaunchKernelGGL((eval_rowrot<T, O, DERIV_, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, \
+                           prm, n, out, ostride, w, s->bad);                                                            \
+    } while (0)
+#define BSK_ROWROT_ND(DERIV_)                                                                                            \
+    switch (s->nDep) {                                                                                                   \
+    case 1: BSK_ROWROT(DERIV_, 1); break;                                                                                \
+    case 2: BSK_ROWROT(DERIV_, 2); break;                                                                                \
+    case 3: BSK_ROWROT(DERIV_, 3); break;                                                                                \
+    default: BSK_ROWROT(DERIV_, 0); break;                                                                               \
+    }
+            if (deriv) { BSK_ROWROT_ND(true); } else { BSK_ROWROT_ND(false); }
+#undef BSK_ROWROT_ND
+#undef BSK_ROWROT
             HIPCHK(hipGetLastError());
             return BSK_OK;
         }

@@ -49,7 +49,7 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
     for (int i = threadIdx.x; i < td.lut_len; i += bd) slut[i] = glut[i];
 }
 
-template <typename T, int O, bool DERIV>
+template <typename T, int O, bool DERIV, int ND>
 __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                     const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                     const T *__restrict__ gcoef, const Params<T> prm,
@@ -81,6 +81,12 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
     T un[2] = {lo0, lo1};
     if (n < N) { un[0] = prm.p[0][n]; un[1] = prm.p[1][n]; }
+    // The first parameters must have landed before the loop: hipcc merges wait-count state at the
+    // loop header, and a load still pending here makes it wait for the prefetch below right after
+    // issuing it, in every iteration.
+    asm volatile("" : "+v"(un[0]), "+v"(un[1]));
+    const int nDep = ND > 0 ? ND : d.nDep;   // ND > 0: the store count per iteration is a constant,
+                                             // so the prefetch is awaited with a counted vmcnt
 
     for (; n < N; n += stride) {
         const T u[2] = {un[0], un[1]};
@@ -105,7 +111,8 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
         for (int a = 0; a < O; ++a)
             ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
 
-        for (int dep = 0; dep < d.nDep; ++dep) {
+#pragma unroll
+        for (int dep = 0; dep < nDep; ++dep) {
             T c[O][O];
 #pragma unroll
             for (int a = 0; a < O; ++a) lds_issue_row<T, O>(ra[a], c[a]);
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 // NORMAL = true (surfaces in 3-D, nDep == 3): the two tangents stay in registers and the kernel
 // writes the normal (cross product, reference bspy/_spline_evaluation.py:215-246: optional unit
 // length, optional negation) instead of the six partials: out[i * N + n], i < 3.
-template <typename T, int O, bool NORMAL>
+template <typename T, int O, bool NORMAL, int ND>
 __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                    const T *__restrict__ gcoef, const Params<T> prm,
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
     const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
     T un[2] = {lo0, lo1};
     if (n < N) { un[0] = prm.p[0][n]; un[1] = prm.p[1][n]; }
+    asm volatile("" : "+v"(un[0]), "+v"(un[1]));   // see eval_rowrot: no load pending at the loop header
 
     for (; n < N; n += stride) {
         const T u[2] = {un[0], un[1]};
@@ -197,8 +205,8 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
             ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
 
         T su[3], sv[3];                    // NORMAL: the two tangent vectors
-        const int ndep = NORMAL ? 3 : d.nDep;
-#pragma unroll 3
+        const int ndep = NORMAL ? 3 : (ND > 0 ? ND : d.nDep);
+#pragma unroll
         for (int dep = 0; dep < ndep; ++dep) {
             T c[O][O];
 #pragma unroll

@@ -280,6 +280,9 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
         un[iv] = lo_r[iv];
         if (n < N) un[iv] = prm.p[iv][n];
     }
+    // no load may be pending at the loop header (hipcc would then await every prefetch right after issuing it)
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(un[iv]));
 
     for (; n < N; n += stride) {
         T u[NIND];
@@ -434,6 +437,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, cons
     T un[NIND];
 #pragma unroll
     for (int iv = 0; iv < NIND; ++iv) { un[iv] = lo_r[iv]; if (n < N) un[iv] = prm.p[iv][n]; }
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(un[iv]));   // see eval_stream
 
     for (; n < N; n += stride) {
         T u[NIND];
