@@ -470,7 +470,9 @@ static size_t rowrot_lds_bytes(bsk_spline s)
     const TileDesc<T> &tdr = tile_of<T>(s);
     const size_t rs = (size_t)(s->ncoef[1] | 1);
     const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
-    return (size_t)tdr.tab_bytes + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
+    const int nk0 = s->order[0] + s->ncoef[0], nk1 = s->order[1] + s->ncoef[1];
+    const size_t rec_b = s->order[0] == 4 ? rr_records_bytes<T, 4>(nk0, nk1) : rr_records_bytes<T, 2>(nk0, nk1);
+    return rec_b + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
 }
 
 template <typename T>
@@ -487,27 +489,33 @@ static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long lon
     const Desc<T> &d = desc_of<T>(s);
     const TileDesc<T> &tdr = tile_of<T>(s);
     const size_t lds_rr = rowrot_lds_bytes<T>(s);
-    const long long nt = (n + TILE - 1) / TILE;
-    const int g = (int)std::max<long long>(1, std::min<long long>(nt, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
     const T *tab = static_cast<const T *>(s->tab);
     const T *coef = static_cast<const T *>(s->coef);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));
 #define BSK_JROT(O_, ND_)                                                                                               \
     do {                                                                                                                 \
         HIPCHK(allow_lds(jac_rowrot<T, O_, NORMAL, ND_>, lds_rr));                                                      \
         hipLaunchKernelGGL((jac_rowrot<T, O_, NORMAL, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, \
-                           prm, n, out, s->bad, normalize, negate);                                                     \
+                           cp, (unsigned)m, n0, out + n0, n, s->bad, normalize, negate);                                \
     } while (0)
     // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
     const int nd = (NORMAL || s->nDep > 3) ? 0 : s->nDep;
-    if (s->order[0] == 4) {
-        if constexpr (NORMAL) BSK_JROT(4, 0);
-        else switch (nd) { case 1: BSK_JROT(4, 1); break; case 2: BSK_JROT(4, 2); break; case 3: BSK_JROT(4, 3); break; default: BSK_JROT(4, 0); }
-    } else {
-        if constexpr (NORMAL) BSK_JROT(2, 0);
-        else switch (nd) { case 1: BSK_JROT(2, 1); break; case 2: BSK_JROT(2, 2); break; case 3: BSK_JROT(2, 3); break; default: BSK_JROT(2, 0); }
+    // 32-bit point indices inside a launch: chunks of at most RR_MAX_CHUNK points
+    for (long long n0 = 0; n0 < n; n0 += RR_MAX_CHUNK) {
+        const long long m = std::min<long long>(n - n0, RR_MAX_CHUNK);
+        const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu));
+        Params<T> cp = prm;
+        for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
+        if (s->order[0] == 4) {
+            if constexpr (NORMAL) BSK_JROT(4, 0);
+            else switch (nd) { case 1: BSK_JROT(4, 1); break; case 2: BSK_JROT(4, 2); break; case 3: BSK_JROT(4, 3); break; default: BSK_JROT(4, 0); }
+        } else {
+            if constexpr (NORMAL) BSK_JROT(2, 0);
+            else switch (nd) { case 1: BSK_JROT(2, 1); break; case 2: BSK_JROT(2, 2); break; case 3: BSK_JROT(2, 3); break; default: BSK_JROT(2, 0); }
+        }
+        HIPCHK(hipGetLastError());
     }
 #undef BSK_JROT
-    HIPCHK(hipGetLastError());
     return BSK_OK;
 }
 
@@ -526,13 +534,13 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
         // surfaces of order 2 / 4: row rotation on an odd-stride LDS image
         if (rowrot_applies<T>(s)) {
             const size_t lds_rr = rowrot_lds_bytes<T>(s);
-            const int g = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr))));
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));
             // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
 #define BSK_ROWROT(DERIV_, ND_)                                                                                          \
     do {                                                                                                                 \
         HIPCHK(allow_lds(eval_rowrot<T, O, DERIV_, ND_>, lds_rr));                                                      \
         hipLaunchKernelGGL((eval_rowrot<T, O, DERIV_, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, \
-                           prm, n, out, ostride, w, s->bad);                                                            \
+                           cp, (unsigned)m, n0, out + n0, ostride, w, s->bad);                                          \
     } while (0)
 #define BSK_ROWROT_ND(DERIV_)                                                                                            \
     switch (s->nDep) {                                                                                                   \
@@ -541,10 +549,17 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
     case 3: BSK_ROWROT(DERIV_, 3); break;                                                                                \
     default: BSK_ROWROT(DERIV_, 0); break;                                                                               \
     }
-            if (deriv) { BSK_ROWROT_ND(true); } else { BSK_ROWROT_ND(false); }
+            // 32-bit point indices inside a launch: chunks of at most RR_MAX_CHUNK points
+            for (long long n0 = 0; n0 < n; n0 += RR_MAX_CHUNK) {
+                const long long m = std::min<long long>(n - n0, RR_MAX_CHUNK);
+                const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu));
+                Params<T> cp = prm;
+                for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
+                if (deriv) { BSK_ROWROT_ND(true); } else { BSK_ROWROT_ND(false); }
+                HIPCHK(hipGetLastError());
+            }
 #undef BSK_ROWROT_ND
 #undef BSK_ROWROT
-            HIPCHK(hipGetLastError());
             return BSK_OK;
         }
     }

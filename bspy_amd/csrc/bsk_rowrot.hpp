@@ -17,22 +17,52 @@
 //    order; only the O row sums are combined with a rotation-invariant tree
 //    ((q0 + q2) + (q1 + q3), separately rounded), so the result does not depend on the rank:
 //    runs stay bitwise reproducible and independent of a point's position in the batch.
+//
+// The loop is VALU- and latency-bound rather than conflict-bound (tools/conflict_probe.py: a
+// conflict-free batch runs only 12 % faster than a random one), so the instruction count per
+// point is trimmed as well:
+//  * knots and reciprocal rows are staged as per-knot RECORDS {k[i], r1[i], .., r(O-1)[i]} of odd
+//    stride (O | 1 elements): every table read of a variable is one address register plus a
+//    compile-time offset, and the banks still spread like the flat rows;
+//  * a bucket whose bracket holds at most two spans (lut_steps == 1: every well-conditioned knot
+//    vector) takes one compare instead of the bisection loop;
+//  * point indices are 32 bit (the launcher cuts batches into chunks of at most 2^28 points) and
+//    parameters / results are addressed as scalar base + 32-bit byte offset;
+//  * the prefetch of the next parameters is unconditional (clamped index), so its wait is a
+//    counted vmcnt at the end of the iteration;
+//  * integer multiplies are 24 bit (v_mad_u32_u24 is full rate, v_mul_lo_u32 quarter rate).
 #pragma once
 #include "bsk_stream.hpp"
 
 namespace bsk {
 
+constexpr unsigned RR_MAX_CHUNK = 1u << 28;   // points per launch (32-bit byte offsets: 8 B * 2^28 = 2 GiB)
+
+// LDS image of the rowrot kernels (bytes, 16-byte aligned parts):
+//   [axis records: (nk0 + nk1) x (O | 1) x T] [bucket tables] [coefficients, odd row stride] [rank counters]
+template <typename T, int O>
+__host__ __device__ constexpr unsigned rr_rec_bytes() { return (unsigned)((O | 1) * sizeof(T)); }
+
+template <typename T, int O>
+__host__ __device__ inline unsigned rr_records_bytes(int nk0, int nk1)
+{
+    return ((unsigned)(nk0 + nk1) * rr_rec_bytes<T, O>() + 15u) & ~15u;
+}
+
 // Copy the table image into LDS with several global loads in flight per lane (the plain
 // `s[i] = g[i]` loop compiles to load - wait - write, one L2 round trip per element: ~13 round
-// trips for the 104 KB image).  Coefficient rows get the odd stride rs.
-template <typename T>
+// trips for the 104 KB image).  Coefficient rows get the odd stride rs; the axis tables are
+// transposed into per-knot records.
+template <typename T, int O>
 __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d, const TileDesc<T> &td,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                    const T *__restrict__ gcoef, int nc1, int rs)
 {
-    T *stab = reinterpret_cast<T *>(smem);
-    unsigned *slut = reinterpret_cast<unsigned *>(smem + td.tab_bytes);
-    T *scoef = reinterpret_cast<T *>(smem + td.tab_bytes + td.lut_bytes);
+    constexpr int REC = O | 1;
+    const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
+    T *srec = reinterpret_cast<T *>(smem);
+    unsigned *slut = reinterpret_cast<unsigned *>(smem + rec_bytes);
+    T *scoef = reinterpret_cast<T *>(smem + rec_bytes + td.lut_bytes);
     constexpr int U = 8;
     const int bd = blockDim.x;
     for (int i0 = threadIdx.x; i0 < d.coef_len; i0 += bd * U) {
@@ -45,30 +75,157 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
             if (i < d.coef_len) { const int row = i / nc1, col = i - row * nc1; scoef[row * rs + col] = v[k]; }
         }
     }
-    for (int i = threadIdx.x; i < d.tab_len; i += bd) stab[i] = gtab[i];
+#pragma unroll
+    for (int iv = 0; iv < 2; ++iv) {
+        const T *t = gtab + d.off[iv];
+        const int nk = d.nk[iv];
+        T *r = srec + (iv ? d.nk[0] * REC : 0);
+        for (int i = threadIdx.x; i < nk * O; i += bd) {
+            const int D = i / nk, k = i - D * nk;
+            r[k * REC + D] = t[i];
+        }
+    }
     for (int i = threadIdx.x; i < td.lut_len; i += bd) slut[i] = glut[i];
 }
 
+// Reads of one variable's span from its records, base rb = address of record ix - (O - 1):
+// the O - 1 knots, then per level D the D reciprocals r_D[ix - D .. ix - 1] (same order as
+// bases_all, so bases_compute's counted waits apply unchanged).
+template <typename T, int O, int J = 0>
+__device__ __forceinline__ void rr_issue_knots(unsigned rb, T (&kn)[O])
+{
+    if constexpr (J < O - 1) {
+        kn[J] = LdsRead<T>::template at<J * (int)rr_rec_bytes<T, O>()>(rb);
+        rr_issue_knots<T, O, J + 1>(rb, kn);
+    }
+}
+template <typename T, int O, int D, int J = 0>
+__device__ __forceinline__ void rr_issue_level(unsigned rb, T (&rc)[O])
+{
+    if constexpr (J < D) {
+        rc[J] = LdsRead<T>::template at<(O - 1 - D + J) * (int)rr_rec_bytes<T, O>() + D * (int)sizeof(T)>(rb);
+        rr_issue_level<T, O, D, J + 1>(rb, rc);
+    }
+}
+template <typename T, int O, int D = 1>
+__device__ __forceinline__ void rr_issue_levels(unsigned rb, T (&rc)[O][O])
+{
+    if constexpr (D < O) {
+        rr_issue_level<T, O, D>(rb, rc[D]);
+        rr_issue_levels<T, O, D + 1>(rb, rc);
+    }
+}
+template <typename T, int O>
+__device__ __forceinline__ void rr_issue_tables(const unsigned (&rec_a)[2], const int (&ix)[2], T (&kn)[2][O], T (&rc)[2][O][O])
+{
+#pragma unroll
+    for (int iv = 0; iv < 2; ++iv) {
+        const unsigned rb = rec_a[iv] + __umul24((unsigned)(ix[iv] - (O - 1)), rr_rec_bytes<T, O>());
+        rr_issue_knots<T, O>(rb, kn[iv]);
+        rr_issue_levels<T, O>(rb, rc[iv]);
+    }
+}
+
+// Span search of both variables in lock step through the bucket tables (see find_spans), knots
+// read from the records.  NANFIX: a NaN parameter takes the last span like the reference's
+// searchsorted (only derivative levels can tell: value levels turn every basis value into NaN).
+template <typename T, int O, bool NANFIX>
+__device__ __forceinline__ void rr_find_spans(const unsigned (&rec_a)[2], unsigned lut_a, const Desc<T> &d,
+                                              const TileDesc<T> &td, int steps, const T (&u)[2], int (&ix)[2])
+{
+    constexpr unsigned RB = rr_rec_bytes<T, O>();
+    unsigned e[2];
+#pragma unroll
+    for (int iv = 0; iv < 2; ++iv) {
+        int b = (int)((u[iv] - d.lo[iv]) * td.lut_scale[iv]);
+        b = min(max(b, 0), td.lut_m[iv] - 1);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(e[iv]) : "v"(lut_a + 4u * (unsigned)td.lut_off[iv] + 4u * (unsigned)b) : "memory");
+    }
+    lds_wait_n<0, 2>(e);
+    int l[2], h[2];
+#pragma unroll
+    for (int iv = 0; iv < 2; ++iv) { l[iv] = (int)(e[iv] & 0xffffu); h[iv] = (int)(e[iv] >> 16); }
+    if (steps == 1) {
+        // every bracket holds at most two spans: one compare against the knot between them
+        T km[2];
+#pragma unroll
+        for (int iv = 0; iv < 2; ++iv) km[iv] = LdsRead<T>::template at<0>(rec_a[iv] + __umul24((unsigned)l[iv], RB));
+        lds_wait_n<0, 2>(km);
+#pragma unroll
+        for (int iv = 0; iv < 2; ++iv) l[iv] += (int)((l[iv] < h[iv]) & (km[iv] <= u[iv]));
+    } else {
+        for (int s = 0; s < steps; ++s) {
+            T km[2];
+#pragma unroll
+            for (int iv = 0; iv < 2; ++iv)
+                km[iv] = LdsRead<T>::template at<0>(rec_a[iv] + __umul24((unsigned)((l[iv] + h[iv]) >> 1), RB));
+            lds_wait_n<0, 2>(km);
+#pragma unroll
+            for (int iv = 0; iv < 2; ++iv) {
+                const int mid = (l[iv] + h[iv]) >> 1;
+                const bool open = l[iv] < h[iv];
+                const bool right = open && (km[iv] <= u[iv]);
+                const bool left = open && !right;
+                l[iv] = right ? mid + 1 : l[iv];
+                h[iv] = left ? mid : h[iv];
+            }
+        }
+    }
+#pragma unroll
+    for (int iv = 0; iv < 2; ++iv) ix[iv] = (NANFIX && u[iv] != u[iv]) ? d.ncoef[iv] : l[iv];
+}
+
+// Addresses of the O window rows in rank-rotated order and the rotation rank itself.
+// (A row stride of 32 / O mod 32 with lanes ranked inside groups of 32 / O classes makes the
+// rotation a pure bank shift - Monte Carlo multiplicity 2.11 against 2.37 - but measured the same
+// time on MI355X and needs up to 31 pad elements per row: not kept.)
+template <typename T, int O>
+__device__ __forceinline__ int rr_rows(unsigned coef_a, int rs, unsigned rstride, const int (&ix)[2], unsigned *s_rc,
+                                       int lane, unsigned (&ra)[O])
+{
+    const int base = (int)__umul24((unsigned)(ix[0] - O), (unsigned)rs) + (ix[1] - O);
+    s_rc[lane] = 0u;
+    const int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+    const unsigned a0 = coef_a + (unsigned)base * (unsigned)sizeof(T);
+#pragma unroll
+    for (int a = 0; a < O; ++a) ra[a] = a0 + __umul24((unsigned)((a + rho) & (O - 1)), rstride);
+    return rho;
+}
+
+template <typename T>
+__device__ __forceinline__ T rr_load(const T *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void rr_store(T *base, unsigned byte_off, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+// N <= RR_MAX_CHUNK points of one launch; n0 = index of its first point in the caller's batch
+// (for the out-of-domain record); out[dep * ostride + n].
 template <typename T, int O, bool DERIV, int ND>
 __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                     const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                     const T *__restrict__ gcoef, const Params<T> prm,
-                                                    const long long N, T *__restrict__ out, const long long ostride,
-                                                    const Wrt wrt, unsigned long long *bad)
+                                                    const unsigned N, const long long n0, T *__restrict__ out,
+                                                    const long long ostride, const Wrt wrt, unsigned long long *bad)
 {
     static_assert(O == 2 || O == 4, "row rotation covers orders 2 and 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned tab_a = (unsigned)(size_t)smem;
-    const unsigned lut_a = tab_a + td.tab_bytes;
+    const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
+    const unsigned rec_a[2] = {(unsigned)(size_t)smem, (unsigned)(size_t)smem + (unsigned)d.nk[0] * rr_rec_bytes<T, O>()};
+    const unsigned lut_a = rec_a[0] + rec_bytes;
     const unsigned coef_a = lut_a + td.lut_bytes;
     const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
     const int rs = nc1 | 1;                                   // odd LDS row stride (elements)
     const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
     const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
-    stage_image_rowrot<T>(smem, d, td, gtab, glut, gcoef, nc1, rs);
+    stage_image_rowrot<T, O>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
     // per-wave class counters of the rank rotation: [wave][half-wave][class]
-    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes +
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + td.lut_bytes +
                                                  (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
     const int lane = threadIdx.x & 63;
 
@@ -76,11 +233,12 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     // Wave-granular round robin: consecutive 64-point wave tiles go to different workgroups
     // (global wave = wave-in-block * gridDim + block), so the ragged last round is spread over
     // all CUs instead of keeping a few workgroups busy for one more full iteration.
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long n = ((long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64 + lane;
+    const unsigned stride = gridDim.x * (unsigned)TILE;
+    unsigned n = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64u + (unsigned)lane;
     const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
+    const T *p0 = prm.p[0], *p1 = prm.p[1];
     T un[2] = {lo0, lo1};
-    if (n < N) { un[0] = prm.p[0][n]; un[1] = prm.p[1][n]; }
+    if (n < N) { un[0] = rr_load(p0, n * (unsigned)sizeof(T)); un[1] = rr_load(p1, n * (unsigned)sizeof(T)); }
     // The first parameters must have landed before the loop: hipcc merges wait-count state at the
     // loop header, and a load still pending here makes it wait for the prefetch below right after
     // issuing it, in every iteration.
@@ -91,26 +249,30 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     for (; n < N; n += stride) {
         const T u[2] = {un[0], un[1]};
         const bool outside = (u[0] < lo0) | (u[0] > hi0) | (u[1] < lo1) | (u[1] > hi1);
-        un[0] = lo0; un[1] = lo1;
-        if (n + stride < N) { un[0] = prm.p[0][n + stride]; un[1] = prm.p[1][n + stride]; }
-        if (outside) record_bad(bad, n);
+        {
+            const unsigned nn = min(n + stride, N - 1u) * (unsigned)sizeof(T);
+            un[0] = rr_load(p0, nn);
+            un[1] = rr_load(p1, nn);
+        }
+        if (outside) record_bad(bad, n0 + (long long)n);
 
         int ix[2];
-        find_spans<T, 2>(tab_a, lut_a, d, td, steps, u, ix);
+        rr_find_spans<T, O, DERIV>(rec_a, lut_a, d, td, steps, u, ix);
         T b[2][O];
-        bases_all<T, 2, O, DERIV>(tab_a, d, ix, u, wrt, b);
+        {
+            T kn[2][O], rc[2][O][O];
+            rr_issue_tables<T, O>(rec_a, ix, kn, rc);
+            bases_compute<T, 2, O, DERIV, 0>(u, wrt, kn, rc, b);
+        }
 
-        const int base = (ix[0] - O) * rs + (ix[1] - O);
-        s_rc[lane] = 0u;
-        int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+        unsigned ra[O];
+        const int rho = rr_rows<T, O>(coef_a, rs, rstride, ix, s_rc, lane, ra);
         // rotated row order: step a reads window row (a + rho) mod O, weighted by b0 of that row
         T b0r[O];
         rotate_basis_values<T, O>(b[0], rho, b0r);
-        unsigned ra[O];
-#pragma unroll
-        for (int a = 0; a < O; ++a)
-            ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
 
+        const unsigned off = n * (unsigned)sizeof(T);
+        T *o = out;
 #pragma unroll
         for (int dep = 0; dep < nDep; ++dep) {
             T c[O][O];
@@ -128,7 +290,8 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
             T r;
             if constexpr (O == 2) r = add_rn<T>(q[0], q[1]);
             else r = add_rn<T>(add_rn<T>(q[0], q[2]), add_rn<T>(q[1], q[3]));
-            out[dep * ostride + n] = r;
+            rr_store(o, off, r);
+            o += ostride;
 #pragma unroll
             for (int a = 0; a < O; ++a) ra[a] += dstride;
         }
@@ -138,72 +301,68 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 // jac_rowrot: the fused jacobian (see jac_stream) on the odd-stride image with row rotation.
 // Per dependent variable the window is read once; every row gives t_a = sum_k c[a][k] b1[k] and
 // td_a = sum_k c[a][k] db1[k]; du = sum_a t_a db0[a] and dv = sum_a td_a b0[a] are combined with
-// the rotation-invariant tree.  out[(dep * 2 + j) * N + n]
+// the rotation-invariant tree.  out[(dep * 2 + j) * ostride + n]
 // NORMAL = true (surfaces in 3-D, nDep == 3): the two tangents stay in registers and the kernel
 // writes the normal (cross product, reference bspy/_spline_evaluation.py:215-246: optional unit
-// length, optional negation) instead of the six partials: out[i * N + n], i < 3.
+// length, optional negation) instead of the six partials: out[i * ostride + n], i < 3.
 template <typename T, int O, bool NORMAL, int ND>
 __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDesc<T> td,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                    const T *__restrict__ gcoef, const Params<T> prm,
-                                                   const long long N, T *__restrict__ out, unsigned long long *bad,
+                                                   const unsigned N, const long long n0, T *__restrict__ out,
+                                                   const long long ostride, unsigned long long *bad,
                                                    const int normalize, const int negate)
 {
     static_assert(O == 2 || O == 4, "row rotation covers orders 2 and 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned tab_a = (unsigned)(size_t)smem;
-    const unsigned lut_a = tab_a + td.tab_bytes;
+    const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
+    const unsigned rec_a[2] = {(unsigned)(size_t)smem, (unsigned)(size_t)smem + (unsigned)d.nk[0] * rr_rec_bytes<T, O>()};
+    const unsigned lut_a = rec_a[0] + rec_bytes;
     const unsigned coef_a = lut_a + td.lut_bytes;
     const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
     const int rs = nc1 | 1;
+    const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
     const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
-    stage_image_rowrot<T>(smem, d, td, gtab, glut, gcoef, nc1, rs);
+    stage_image_rowrot<T, O>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
-    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + td.tab_bytes + td.lut_bytes +
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + td.lut_bytes +
                                                  (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
     const int lane = threadIdx.x & 63;
     const int steps = td.lut_steps[0] > td.lut_steps[1] ? td.lut_steps[0] : td.lut_steps[1];
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long n = ((long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64 + lane;
+    const unsigned stride = gridDim.x * (unsigned)TILE;
+    unsigned n = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64u + (unsigned)lane;
     const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
+    const T *p0 = prm.p[0], *p1 = prm.p[1];
     T un[2] = {lo0, lo1};
-    if (n < N) { un[0] = prm.p[0][n]; un[1] = prm.p[1][n]; }
+    if (n < N) { un[0] = rr_load(p0, n * (unsigned)sizeof(T)); un[1] = rr_load(p1, n * (unsigned)sizeof(T)); }
     asm volatile("" : "+v"(un[0]), "+v"(un[1]));   // see eval_rowrot: no load pending at the loop header
 
     for (; n < N; n += stride) {
         const T u[2] = {un[0], un[1]};
         const bool outside = (u[0] < lo0) | (u[0] > hi0) | (u[1] < lo1) | (u[1] > hi1);
-        un[0] = lo0; un[1] = lo1;
-        if (n + stride < N) { un[0] = prm.p[0][n + stride]; un[1] = prm.p[1][n + stride]; }
-        if (outside) record_bad(bad, n);
+        {
+            const unsigned nn = min(n + stride, N - 1u) * (unsigned)sizeof(T);
+            un[0] = rr_load(p0, nn);
+            un[1] = rr_load(p1, nn);
+        }
+        if (outside) record_bad(bad, n0 + (long long)n);
 
         int ix[2];
-        find_spans<T, 2>(tab_a, lut_a, d, td, steps, u, ix);
+        rr_find_spans<T, O, true>(rec_a, lut_a, d, td, steps, u, ix);
         T b[2][O], db[2][O];
         {
-            T kn[2][O];
-            T rc[2][O][O];
-            if constexpr (O > 1) {
-#pragma unroll
-                for (int iv = 0; iv < 2; ++iv) {
-                    const unsigned ta = tab_a + (unsigned)d.off[iv] * (unsigned)sizeof(T);
-                    lds_issue_n<T, O - 1, O>(ta + (unsigned)(ix[iv] - (O - 1)) * (unsigned)sizeof(T), kn[iv]);
-                    basis_issue<T, O, 1>(ta, d.nk[iv], ix[iv], rc[iv]);
-                }
-            }
+            T kn[2][O], rc[2][O][O];
+            rr_issue_tables<T, O>(rec_a, ix, kn, rc);
             bases_d1_compute<T, 2, O, 0>(u, kn, rc, b, db);
         }
-        const int base = (ix[0] - O) * rs + (ix[1] - O);
-        s_rc[lane] = 0u;
-        const int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+        unsigned ra[O];
+        const int rho = rr_rows<T, O>(coef_a, rs, rstride, ix, s_rc, lane, ra);
         T b0r[O], db0r[O];
         rotate_basis_values<T, O>(b[0], rho, b0r);
         rotate_basis_values<T, O>(db[0], rho, db0r);
-        unsigned ra[O];
-#pragma unroll
-        for (int a = 0; a < O; ++a)
-            ra[a] = coef_a + (unsigned)(base + ((a + rho) & (O - 1)) * rs) * (unsigned)sizeof(T);
 
+        const unsigned off = n * (unsigned)sizeof(T);
+        T *o = out;
         T su[3], sv[3];                    // NORMAL: the two tangent vectors
         const int ndep = NORMAL ? 3 : (ND > 0 ? ND : d.nDep);
 #pragma unroll
@@ -234,9 +393,9 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
                 else if (dep == 1) { su[1] = du; sv[1] = dv; }
                 else { su[2] = du; sv[2] = dv; }
             } else {
-                T *o = out + (long long)dep * 2 * N + n;
-                o[0] = du;
-                o[N] = dv;
+                rr_store(o, off, du);
+                rr_store(o + ostride, off, dv);
+                o += 2 * ostride;
             }
 #pragma unroll
             for (int a = 0; a < O; ++a) ra[a] += dstride;
@@ -251,9 +410,9 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
                 const T len = sqrt(nx * nx + ny * ny + nz * nz);
                 nx = nx / len; ny = ny / len; nz = nz / len;
             }
-            out[n] = nx;
-            out[N + n] = ny;
-            out[2 * N + n] = nz;
+            rr_store(out, off, nx);
+            rr_store(out + ostride, off, ny);
+            rr_store(out + 2 * ostride, off, nz);
         }
     }
 }
