@@ -472,7 +472,7 @@ static size_t rowrot_lds_bytes(bsk_spline s)
     const size_t coef_b = ((size_t)s->nDep * s->ncoef[0] * rs * sizeof(T) + 15) & ~(size_t)15;
     const int nk0 = s->order[0] + s->ncoef[0], nk1 = s->order[1] + s->ncoef[1];
     const size_t rec_b = s->order[0] == 4 ? rr_records_bytes<T, 4>(nk0, nk1) : rr_records_bytes<T, 2>(nk0, nk1);
-    return rec_b + tdr.lut_bytes + coef_b + TILE * sizeof(unsigned);
+    return rec_b + rr_lut_bytes<T>(tdr.lut_len) + coef_b + TILE * sizeof(unsigned);
 }
 
 template <typename T>

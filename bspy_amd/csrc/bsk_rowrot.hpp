@@ -39,7 +39,8 @@ namespace bsk {
 constexpr unsigned RR_MAX_CHUNK = 1u << 28;   // points per launch (32-bit byte offsets: 8 B * 2^28 = 2 GiB)
 
 // LDS image of the rowrot kernels (bytes, 16-byte aligned parts):
-//   [axis records: (nk0 + nk1) x (O | 1) x T] [bucket tables] [coefficients, odd row stride] [rank counters]
+//   [axis records: (nk0 + nk1) x (O | 1) x T] [bucket entries: lut_len x RrLutEntry] [coefficients, odd row
+//   stride] [rank counters]
 template <typename T, int O>
 __host__ __device__ constexpr unsigned rr_rec_bytes() { return (unsigned)((O | 1) * sizeof(T)); }
 
@@ -47,6 +48,45 @@ template <typename T, int O>
 __host__ __device__ inline unsigned rr_records_bytes(int nk0, int nk1)
 {
     return ((unsigned)(nk0 + nk1) * rr_rec_bytes<T, O>() + 15u) & ~15u;
+}
+
+// Bucket-table entry of the rowrot image: the packed bracket (lo | hi << 16, see build_lut) and the
+// knot at lo, so the one-compare search needs a single LDS round trip (one 16- / 8-byte read).
+template <typename T>
+struct RrLutEntry;
+template <>
+struct RrLutEntry<double> {
+    unsigned e, pad;
+    double km;
+    typedef unsigned raw __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ raw read(unsigned addr)
+    {
+        raw r;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+        return r;
+    }
+    static __device__ __forceinline__ double knot(const raw &r)
+    {
+        return __hiloint2double((int)r.w, (int)r.z);
+    }
+};
+template <>
+struct RrLutEntry<float> {
+    unsigned e;
+    float km;
+    typedef unsigned raw __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ raw read(unsigned addr)
+    {
+        raw r;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+        return r;
+    }
+    static __device__ __forceinline__ float knot(const raw &r) { return __uint_as_float(r.y); }
+};
+template <typename T>
+__host__ __device__ inline unsigned rr_lut_bytes(int lut_len)
+{
+    return ((unsigned)lut_len * (unsigned)sizeof(RrLutEntry<T>) + 15u) & ~15u;
 }
 
 // Copy the table image into LDS with several global loads in flight per lane (the plain
@@ -61,8 +101,8 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
     constexpr int REC = O | 1;
     const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
     T *srec = reinterpret_cast<T *>(smem);
-    unsigned *slut = reinterpret_cast<unsigned *>(smem + rec_bytes);
-    T *scoef = reinterpret_cast<T *>(smem + rec_bytes + td.lut_bytes);
+    RrLutEntry<T> *slut = reinterpret_cast<RrLutEntry<T> *>(smem + rec_bytes);
+    T *scoef = reinterpret_cast<T *>(smem + rec_bytes + rr_lut_bytes<T>(td.lut_len));
     constexpr int U = 8;
     const int bd = blockDim.x;
     for (int i0 = threadIdx.x; i0 < d.coef_len; i0 += bd * U) {
@@ -85,7 +125,12 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
             r[k * REC + D] = t[i];
         }
     }
-    for (int i = threadIdx.x; i < td.lut_len; i += bd) slut[i] = glut[i];
+    for (int i = threadIdx.x; i < td.lut_len; i += bd) {
+        const unsigned e = glut[i];
+        const int iv = i >= td.lut_off[1] ? 1 : 0;
+        slut[i].e = e;
+        slut[i].km = gtab[d.off[iv] + (int)(e & 0xffffu)];
+    }
 }
 
 // Reads of one variable's span from its records, base rb = address of record ix - (O - 1):
@@ -134,25 +179,23 @@ __device__ __forceinline__ void rr_find_spans(const unsigned (&rec_a)[2], unsign
                                               const TileDesc<T> &td, int steps, const T (&u)[2], int (&ix)[2])
 {
     constexpr unsigned RB = rr_rec_bytes<T, O>();
-    unsigned e[2];
+    constexpr unsigned EB = (unsigned)sizeof(RrLutEntry<T>);
+    typename RrLutEntry<T>::raw e[2];
 #pragma unroll
     for (int iv = 0; iv < 2; ++iv) {
         int b = (int)((u[iv] - d.lo[iv]) * td.lut_scale[iv]);
         b = min(max(b, 0), td.lut_m[iv] - 1);
-        asm volatile("ds_read_b32 %0, %1" : "=v"(e[iv]) : "v"(lut_a + 4u * (unsigned)td.lut_off[iv] + 4u * (unsigned)b) : "memory");
+        e[iv] = RrLutEntry<T>::read(lut_a + EB * (unsigned)td.lut_off[iv] + EB * (unsigned)b);
     }
-    lds_wait_n<0, 2>(e);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]) : : "memory");
     int l[2], h[2];
 #pragma unroll
-    for (int iv = 0; iv < 2; ++iv) { l[iv] = (int)(e[iv] & 0xffffu); h[iv] = (int)(e[iv] >> 16); }
+    for (int iv = 0; iv < 2; ++iv) { l[iv] = (int)(e[iv].x & 0xffffu); h[iv] = (int)(e[iv].x >> 16); }
     if (steps == 1) {
-        // every bracket holds at most two spans: one compare against the knot between them
-        T km[2];
+        // every bracket holds at most two spans: one compare against the knot between them,
+        // which came with the bucket entry
 #pragma unroll
-        for (int iv = 0; iv < 2; ++iv) km[iv] = LdsRead<T>::template at<0>(rec_a[iv] + __umul24((unsigned)l[iv], RB));
-        lds_wait_n<0, 2>(km);
-#pragma unroll
-        for (int iv = 0; iv < 2; ++iv) l[iv] += (int)((l[iv] < h[iv]) & (km[iv] <= u[iv]));
+        for (int iv = 0; iv < 2; ++iv) l[iv] += (int)((l[iv] < h[iv]) & (RrLutEntry<T>::knot(e[iv]) <= u[iv]));
     } else {
         for (int s = 0; s < steps; ++s) {
             T km[2];
@@ -179,13 +222,18 @@ __device__ __forceinline__ void rr_find_spans(const unsigned (&rec_a)[2], unsign
 // (A row stride of 32 / O mod 32 with lanes ranked inside groups of 32 / O classes makes the
 // rotation a pure bank shift - Monte Carlo multiplicity 2.11 against 2.37 - but measured the same
 // time on MI355X and needs up to 31 pad elements per row: not kept.)
-template <typename T, int O>
-__device__ __forceinline__ int rr_rows(unsigned coef_a, int rs, unsigned rstride, const int (&ix)[2], unsigned *s_rc,
-                                       int lane, unsigned (&ra)[O])
+// The rank is requested (counter reset + LDS atomic) BEFORE the table reads of the recursion are
+// issued and consumed after the recursion, so its round trip overlaps theirs.
+__device__ __forceinline__ int rr_rank_request(int base, unsigned *s_rc, int lane)
 {
-    const int base = (int)__umul24((unsigned)(ix[0] - O), (unsigned)rs) + (ix[1] - O);
     s_rc[lane] = 0u;
-    const int rho = (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u) & (O - 1);
+    return (int)atomicAdd(&s_rc[(lane & 32) + (base & 31)], 1u);
+}
+template <typename T, int O>
+__device__ __forceinline__ int rr_rows(unsigned coef_a, int base, int rank, unsigned rstride, unsigned (&ra)[O])
+{
+    asm volatile("" : "+v"(rank));   // first use of the atomic's result: hipcc puts its wait here
+    const int rho = rank & (O - 1);
     const unsigned a0 = coef_a + (unsigned)base * (unsigned)sizeof(T);
 #pragma unroll
     for (int a = 0; a < O; ++a) ra[a] = a0 + __umul24((unsigned)((a + rho) & (O - 1)), rstride);
@@ -217,7 +265,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
     const unsigned rec_a[2] = {(unsigned)(size_t)smem, (unsigned)(size_t)smem + (unsigned)d.nk[0] * rr_rec_bytes<T, O>()};
     const unsigned lut_a = rec_a[0] + rec_bytes;
-    const unsigned coef_a = lut_a + td.lut_bytes;
+    const unsigned coef_a = lut_a + rr_lut_bytes<T>(td.lut_len);
     const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
     const int rs = nc1 | 1;                                   // odd LDS row stride (elements)
     const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
     stage_image_rowrot<T, O>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
     // per-wave class counters of the rank rotation: [wave][half-wave][class]
-    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + td.lut_bytes +
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + rr_lut_bytes<T>(td.lut_len) +
                                                  (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
     const int lane = threadIdx.x & 63;
 
@@ -258,6 +306,8 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 
         int ix[2];
         rr_find_spans<T, O, DERIV>(rec_a, lut_a, d, td, steps, u, ix);
+        const int base = (int)__umul24((unsigned)(ix[0] - O), (unsigned)rs) + (ix[1] - O);
+        const int rank = rr_rank_request(base, s_rc, lane);
         T b[2][O];
         {
             T kn[2][O], rc[2][O][O];
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
         }
 
         unsigned ra[O];
-        const int rho = rr_rows<T, O>(coef_a, rs, rstride, ix, s_rc, lane, ra);
+        const int rho = rr_rows<T, O>(coef_a, base, rank, rstride, ra);
         // rotated row order: step a reads window row (a + rho) mod O, weighted by b0 of that row
         T b0r[O];
         rotate_basis_values<T, O>(b[0], rho, b0r);
@@ -318,14 +368,14 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
     const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
     const unsigned rec_a[2] = {(unsigned)(size_t)smem, (unsigned)(size_t)smem + (unsigned)d.nk[0] * rr_rec_bytes<T, O>()};
     const unsigned lut_a = rec_a[0] + rec_bytes;
-    const unsigned coef_a = lut_a + td.lut_bytes;
+    const unsigned coef_a = lut_a + rr_lut_bytes<T>(td.lut_len);
     const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
     const int rs = nc1 | 1;
     const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
     const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
     stage_image_rowrot<T, O>(smem, d, td, gtab, glut, gcoef, nc1, rs);
     __syncthreads();
-    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + td.lut_bytes +
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + rr_lut_bytes<T>(td.lut_len) +
                                                  (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
     const int lane = threadIdx.x & 63;
     const int steps = td.lut_steps[0] > td.lut_steps[1] ? td.lut_steps[0] : td.lut_steps[1];
@@ -349,6 +399,8 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
 
         int ix[2];
         rr_find_spans<T, O, true>(rec_a, lut_a, d, td, steps, u, ix);
+        const int base = (int)__umul24((unsigned)(ix[0] - O), (unsigned)rs) + (ix[1] - O);
+        const int rank = rr_rank_request(base, s_rc, lane);
         T b[2][O], db[2][O];
         {
             T kn[2][O], rc[2][O][O];
@@ -356,7 +408,7 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
             bases_d1_compute<T, 2, O, 0>(u, kn, rc, b, db);
         }
         unsigned ra[O];
-        const int rho = rr_rows<T, O>(coef_a, rs, rstride, ix, s_rc, lane, ra);
+        const int rho = rr_rows<T, O>(coef_a, base, rank, rstride, ra);
         T b0r[O], db0r[O];
         rotate_basis_values<T, O>(b[0], rho, b0r);
         rotate_basis_values<T, O>(db[0], rho, db0r);

@@ -241,3 +241,84 @@ def test_collocation_derivative_orders():
     from bspy_amd.collocation import derivative_orders
     assert derivative_orders([0, 0, 0.1, 0.2, 0.2, 0.2, 0.3]).tolist() == [0, 1, 0, 0, 1, 2, 0]
     assert derivative_orders([]).tolist() == []
+
+
+# ---------------------------------------------------------------------------------------------
+# build-time guard of the inline-asm LDS kernels (bspy_amd/csrc/check_lds_hazards.py)
+# ---------------------------------------------------------------------------------------------
+def _hazards(body):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "check_lds_hazards", os.path.join(ROOT, "bspy_amd", "csrc", "check_lds_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = list(enumerate(("_ZN3bsk11eval_rowrotEv:\n" + body + "\ts_endpgm\n").splitlines(True), 1))
+    return mod.check_kernel("k", lines[1:])
+
+
+def test_lds_hazard_checker_accepts_counted_waits():
+    ok = """
+\tds_read_b64 v[10:11], v2 offset:0
+\tds_read_b64 v[12:13], v2 offset:8
+\tv_add_u32_e32 v3, 1, v3
+\ts_waitcnt lgkmcnt(1)
+\tv_mul_f64 v[20:21], v[10:11], v[4:5]
+\ts_waitcnt lgkmcnt(0)
+\tv_mul_f64 v[22:23], v[12:13], v[4:5]
+"""
+    assert _hazards(ok) == []
+
+
+def test_lds_hazard_checker_flags_use_before_wait():
+    copy_before_wait = """
+\tds_read_b64 v[10:11], v2 offset:0
+\tds_read_b64 v[12:13], v2 offset:8
+\ts_waitcnt lgkmcnt(1)
+\tv_mov_b32_e32 v30, v12
+\ts_waitcnt lgkmcnt(0)
+"""
+    errs = _hazards(copy_before_wait)
+    assert len(errs) == 1 and "v12" in errs[0][1]
+    overwritten = """
+\tds_read_b32 v7, v2
+\tv_mov_b32_e32 v7, 0
+\ts_waitcnt lgkmcnt(0)
+"""
+    assert len(_hazards(overwritten)) == 1
+    # packed fp32 math names a pair but reads only the selected halves
+    packed = """
+\tds_read_b32 v11, v2
+\tv_pk_mul_f32 v[32:33], v[4:5], v[10:11] op_sel_hi:[1,0]
+\ts_waitcnt lgkmcnt(0)
+"""
+    assert _hazards(packed) == []
+    assert len(_hazards(packed.replace(" op_sel_hi:[1,0]", ""))) == 1
+
+
+def test_lds_hazard_checker_follows_control_flow():
+    # the read is awaited on one path only: the use after the join is a hazard
+    one_sided = """
+\tds_read_b64 v[10:11], v2 offset:0
+\ts_cbranch_vccnz .LBB0_2
+\ts_waitcnt lgkmcnt(0)
+.LBB0_2:
+\tv_add_f64 v[20:21], v[10:11], v[4:5]
+"""
+    assert len(_hazards(one_sided)) == 1
+    # a read left in flight around a loop piles up
+    loop = """
+.LBB0_1:
+\tds_read_b64 v[10:11], v2 offset:0
+\ts_cbranch_vccnz .LBB0_1
+\ts_waitcnt lgkmcnt(0)
+"""
+    assert len(_hazards(loop)) >= 1
+    # drained before the back edge: fine
+    drained = """
+.LBB0_1:
+\tds_read_b64 v[10:11], v2 offset:0
+\ts_waitcnt lgkmcnt(0)
+\tv_add_f64 v[20:21], v[10:11], v[4:5]
+\ts_cbranch_vccnz .LBB0_1
+"""
+    assert _hazards(drained) == []
