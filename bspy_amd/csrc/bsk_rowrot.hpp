@@ -31,6 +31,9 @@
 //  * the prefetch of the next parameters is unconditional (clamped index), so its wait is a
 //    counted vmcnt at the end of the iteration;
 //  * integer multiplies are 24 bit (v_mad_u32_u24 is full rate, v_mul_lo_u32 quarter rate).
+// Tried on top of this and measured no faster (kept out): two window buffers per lane (next
+// variable's reads in flight during the contraction), two consecutive points per lane with
+// 16-byte parameter loads / result stores, knot and reciprocal rows through the vector L1.
 #pragma once
 #include "bsk_stream.hpp"
 
@@ -245,10 +248,12 @@ __device__ __forceinline__ T rr_load(const T *base, unsigned byte_off)
 {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
+// Results are written once and never read by the kernel: non-temporal stores (measured 6 % on
+// the whole cfg2 kernel; non-temporal parameter LOADS measured slightly slower and are not used).
 template <typename T>
 __device__ __forceinline__ void rr_store(T *base, unsigned byte_off, T v)
 {
-    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off));
 }
 
 // N <= RR_MAX_CHUNK points of one launch; n0 = index of its first point in the caller's batch

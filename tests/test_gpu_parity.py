@@ -322,6 +322,46 @@ def test_empty_and_ragged():
         assert np.abs(out - orc).max() <= 1e-12 * _scale(orc)
 
 
+def test_pair_kernels_odd_sizes_views_and_domain_index():
+    """The rowrot kernels give a lane two consecutive points and use 16-byte accesses: odd batch
+    sizes (last lane holds one point), 8-byte-misaligned device views, a jacobian / normal of the
+    same batches, and the first-offender index in either slot of a pair."""
+    torch = pytest.importorskip("torch")
+    c = CASES["cfg2_bicubic"]
+    t = _tables(c)
+    u, v = c.points[0], c.points[1]
+    for n in (1, 2, 3, 5, 127, 128, 129, 2049):
+        pts = [u[:n], v[:n]]
+        for w in ([0, 0], [1, 0], [0, 2]):
+            orc, _ = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, w, pts)
+            assert np.abs(t.evaluate(pts, w) - orc).max() <= 1e-11 * _scale(orc), (n, w)
+        jo, _ = oracle.c_jacobian(c.order, c.nCoef, c.knots, c.coefs, pts)
+        assert np.abs(t.jacobian(pts) - jo).max() <= 1e-11 * _scale(jo), n
+        no, _ = oracle.c_normal(c.order, c.nCoef, c.knots, c.coefs, pts, True, False)
+        assert np.abs(t.normal(pts) - no).max() <= 1e-10, n
+    # device views that start 8 bytes into a 16-byte line, and an output view likewise
+    du = torch.as_tensor(np.concatenate([[0.5], u]), device="cuda")[1:]
+    dv = torch.as_tensor(np.concatenate([[0.5], v, [0.5]]), device="cuda")[1:-1]
+    ref = t.evaluate([u, v])
+    got = t.evaluate_device([du, dv])
+    assert np.array_equal(got.cpu().numpy(), ref)
+    buf = torch.empty(3 * u.size + 1, dtype=torch.float64, device="cuda")
+    got = t.evaluate_device([du, dv], out=buf[1:].view(3, u.size))
+    assert np.array_equal(got.cpu().numpy(), ref)
+    assert np.array_equal(t.jacobian_device([du, dv]).cpu().numpy(), t.jacobian([u, v]))
+    # the first offender is reported whichever slot of its pair it sits in
+    for badi in (10, 11, u.size - 1):
+        ub = u.copy()
+        ub[badi] = 1.5
+        ub[min(badi + 7, u.size - 1)] = -3.0
+        with pytest.raises(bspy_amd.DomainError) as e:
+            t.evaluate([ub, v])
+        assert e.value.index == badi
+        with pytest.raises(bspy_amd.DomainError) as e:
+            t.jacobian([ub[:-1], v[:-1]] if badi < u.size - 1 else [ub, v])
+        assert e.value.index == badi
+
+
 @pytest.mark.parametrize("variant", ["1", "4", "9"])
 def test_kernel_variants(variant, golden_parity, monkeypatch):
     """BSK_VARIANT pins the kernel family (1 eval_fixed, 4 eval_stream, 9 eval_rowrot where it
