@@ -77,7 +77,7 @@ def pmc_traffic(op, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian", "normal"], default="evaluate")
     ap.add_argument("--points", type=int, default=N_POINTS)
