@@ -174,6 +174,14 @@ __device__ __forceinline__ T contract3(CP c, int s0, int s1, const T (&b0)[O], c
     return acc;
 }
 
+// Results are written once and never read back by the kernels: non-temporal stores keep them
+// from displacing the tables in L2 (measured 6 % on the cfg2 kernel).
+template <typename T>
+__device__ __forceinline__ void nt_store(T *p, T v)
+{
+    __builtin_nontemporal_store(v, p);
+}
+
 // Record the smallest out-of-domain point index (rare path).
 __device__ __forceinline__ void record_bad(unsigned long long *bad, long long n)
 {

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void eval_gather(const Desc<T> d, const T *__r
             }
         }
 #pragma unroll
-        for (int dd = 0; dd < ND; ++dd) out[dd * ostride + n] = r[dd];
+        for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + n], r[dd]);
     }
 }
 

@@ -415,13 +415,12 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
                         res[v] = acc;
                     }
                     T *o = out + dep * total + i0 * n1 + c0;
-                    if constexpr (VEC == 4) {
-                        float4 w; w.x = res[0]; w.y = res[1]; w.z = res[2]; w.w = res[3];
-                        *reinterpret_cast<float4 *>(o) = w;
-                    } else {
-                        double2 w; w.x = res[0]; w.y = res[1];
-                        *reinterpret_cast<double2 *>(o) = w;
-                    }
+                    // 16-byte non-temporal store: the grid is written once and not read here
+                    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+                    vec_t w;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) w[v] = res[v];
+                    __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(o));
                 }
             }
         } else {
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
                     T acc = T(0);
 #pragma unroll
                     for (int k = 0; k < O; ++k) acc += rc[k] * b1[k];
-                    out[dep * total + i0 * n1 + i1] = acc;
+                    __builtin_nontemporal_store(acc, &out[dep * total + i0 * n1 + i1]);
                 }
             }
         }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                 T r;
                 if constexpr (NIND == 1) r = row_fma<T, O>(c, b[0]);
                 else r = slab_fma<T, O>(c, b[0], b[1]);
-                out[dep * ostride + n] = r;
+                nt_store(&out[dep * ostride + n], r);
                 caddr += dstride;
             }
         } else {
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
                     block_wait<0>(c);
                     acc += b[0][a] * slab_fma<T, O>(c, b[1], b[2]);
                 }
-                out[dep * ostride + n] = acc;
+                nt_store(&out[dep * ostride + n], acc);
                 caddr += dstride;
             }
         }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, cons
                 T c[1][O];
                 block_issue<T, 1, O>(caddr, 0u, c);
                 block_wait<0>(c);
-                o[0] = row_fma<T, O>(c, db[0]);
+                nt_store(&o[0], row_fma<T, O>(c, db[0]));
             } else if constexpr (NIND == 2) {
                 T c[O][O];
                 block_issue<T, O, O>(caddr, (unsigned)d.cstride[1] * (unsigned)sizeof(T), c);
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, cons
                     j0 += t * db[0][a];
                     j1 += tdv * b[0][a];
                 }
-                o[0] = j0;
-                o[N] = j1;
+                nt_store(&o[0], j0);
+                nt_store(&o[N], j1);
             } else {
                 const unsigned s0 = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
                 const unsigned s1 = (unsigned)d.cstride[2] * (unsigned)sizeof(T);
@@ -520,9 +520,9 @@ __global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, cons
                     j1 += sb * b[0][a];
                     j2 += sc * b[0][a];
                 }
-                o[0] = j0;
-                o[N] = j1;
-                o[2 * N] = j2;
+                nt_store(&o[0], j0);
+                nt_store(&o[N], j1);
+                nt_store(&o[2 * N], j2);
             }
             caddr += dstride;
         }
