@@ -18,7 +18,8 @@ from ._native import BskError, DomainError, NativeLibraryError
 from .device_spline import DeviceSpline, bspline_values_batch, get_device, set_device
 from .spline import Spline
 from .collocation import collocation_matrix
+from .spline_block import SplineBlock
 
-__all__ = ["Spline", "DeviceSpline", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
+__all__ = ["Spline", "SplineBlock", "DeviceSpline", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
            "BskError", "DomainError", "NativeLibraryError"]
 __version__ = "0.1.0"

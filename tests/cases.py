@@ -122,6 +122,62 @@ def parity_cases():
     return cs
 
 
+class BlockCase:
+    """A block of splines (reference bspy/spline_block.py): rows of (map, spline definition) over
+    the block's independent variables, plus a batch of points.  Spline definitions are plain
+    tuples (nInd, nDep, order, nCoef, knots, coefs) so both the reference and this package can
+    build their own Spline objects from them."""
+
+    def __init__(self, name, seed, domains, rows, n, wrts):
+        rng = np.random.default_rng(seed)
+        self.name = name
+        self.nInd = len(domains)
+        self.rows = []
+        for row in rows:
+            new_row = []
+            for (imap, ndep, order, ncoef, cdtype) in row:
+                knots = []
+                for o, c, iv in zip(order, ncoef, imap):
+                    lo, hi = domains[iv]
+                    interior = np.sort(lo + (hi - lo) * (0.05 + 0.9 * rng.random(c - o)))
+                    knots.append(np.concatenate((np.full(o, lo), interior, np.full(o, hi))).astype(np.float64))
+                coefs = rng.standard_normal((ndep, *ncoef)).astype(cdtype)
+                new_row.append((list(imap), (len(imap), ndep, tuple(order), tuple(ncoef), knots, coefs)))
+            self.rows.append(new_row)
+        self.nDep = sum(r[0][1][1] for r in self.rows)
+        self.points = [lo + (hi - lo) * rng.random(n) for (lo, hi) in domains]
+        self.wrts = wrts
+
+
+def block_cases():
+    """SplineBlock evaluation goldens: default maps, mapped
+    variables, single-spline rows and a row summing three splines."""
+    f64, f32 = np.float64, np.float32
+    cs = []
+    # [[F(u,v,w), G(u)], [h(u,v)]] with default maps (consecutive variables per row)
+    cs.append(BlockCase("block_default_maps", 901, [(0.0, 1.0), (-1.0, 2.0), (0.5, 1.5), (0.0, 1.0)],
+                        [[((0, 1, 2), 2, (4, 3, 2), (6, 5, 4), f64), ((3,), 2, (3,), (5,), f64)],
+                         [((0, 1), 1, (4, 3), (6, 5), f64)]], 257,
+                        [(0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 1, 0), (0, 0, 0, 2)]))
+    # mapped variables over (s,t,u,v,w): F(u,v,w) + G(t,s) = 0, h(u,t,w,s) = 0.  (The splines of
+    # a row must map to disjoint variables: the reference constructor rejects anything else,
+    # spline_block.py:88-91, although its docstring example shares a variable.)
+    cs.append(BlockCase("block_mapped", 902, [(0.0, 1.0), (0.0, 2.0), (-1.0, 1.0), (0.0, 1.0), (1.0, 3.0)],
+                        [[((2, 3, 4), 2, (3, 4, 3), (5, 6, 4), f64), ((1, 0), 2, (4, 2), (7, 3), f64)],
+                         [((2, 1, 4, 0), 1, (2, 3, 3, 2), (3, 4, 5, 3), f64)]], 193,
+                        [(0, 0, 0, 0, 0), (0, 0, 1, 0, 0), (1, 0, 0, 1, 0), (0, 1, 0, 0, 0)]))
+    # bicubic surfaces in the fast path: S1(a,b) + S2(d,c) + C(e), and a second row S3(b,a)
+    cs.append(BlockCase("block_surfaces_sum", 903, [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0), (-1.0, 1.0), (0.0, 2.0)],
+                        [[((0, 1), 3, (4, 4), (16, 12), f64), ((3, 2), 3, (4, 4), (9, 10), f64), ((4,), 3, (4,), (7,), f64)],
+                         [((1, 0), 2, (4, 4), (8, 8), f64)]], 1025,
+                        [(0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (0, 1, 1, 0, 0), (0, 0, 0, 0, 2), (0, 0, 0, 1, 0)]))
+    # float32 coefficients decide the block's result dtype (first spline of the first row)
+    cs.append(BlockCase("block_f32_coefs", 904, [(0.0, 1.0), (0.0, 1.0)],
+                        [[((0, 1), 2, (3, 3), (6, 6), f32)], [((1,), 1, (4,), (9,), f32), ((0,), 1, (3,), (5,), f32)]], 129,
+                        [(0, 0), (0, 1)]))
+    return cs
+
+
 def basis_cases():
     """Direct bspline_values goldens: tuples
     (knots, order, u, derivativeOrder, taylorCoefs, explicit_knot_or_None)."""

@@ -209,8 +209,31 @@ def api_semantics(bspy):
     return rec
 
 
+def block_golden(bspy):
+    """SplineBlock evaluation path (reference bspy/spline_block.py:179-247), one point at a time -
+    the reference has no batched block call - on the first 48 points of every block case."""
+    out = {}
+    for c in cases.block_cases():
+        rows = [[(imap, bspy.Spline(*d)) for (imap, d) in row] for row in c.rows]
+        blk = bspy.spline_block.SplineBlock(rows)
+        m = 48
+        pts = np.array([p[:m] for p in c.points])                       # (nInd, m)
+        out[f"{c.name}/nInd_nDep"] = np.array([blk.nInd, blk.nDep])
+        out[f"{c.name}/domain"] = np.asarray(blk.domain(), np.float64)
+        out[f"{c.name}/evaluate"] = np.array([blk.evaluate(pts[:, i]) for i in range(m)], np.float64).T
+        out[f"{c.name}/jacobian"] = np.moveaxis(np.array([blk.jacobian(pts[:, i]) for i in range(m)], np.float64), 0, -1)
+        for w in c.wrts:
+            out[f"{c.name}/wrt_" + "_".join(map(str, w))] = np.array([blk.derivative(w, pts[:, i]) for i in range(m)], np.float64).T
+        out[f"{c.name}/dtype"] = np.array(str(blk.evaluate(pts[:, 0]).dtype))
+        print("block", c.name, "done", flush=True)
+    return out
+
+
 def main():
     bspy = load_reference()
+    if "--only-block" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "block.npz"), **block_golden(bspy))
+        return
     tables, names = reference_tables(bspy)
     np.savez_compressed(os.path.join(HERE, "reference_tables.npz"), **tables)
     with open(os.path.join(HERE, "teapot_names.json"), "w") as f:
@@ -234,6 +257,7 @@ def main():
 
     with open(os.path.join(HERE, "api_semantics.json"), "w") as f:
         json.dump(api_semantics(bspy), f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "block.npz"), **block_golden(bspy))
     print("golden fixtures written to", HERE)
 
 

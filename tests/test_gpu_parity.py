@@ -7,6 +7,8 @@ GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through th
 Tolerances: fp64 1e-10 (BASELINE.json north_star), asserted far tighter (1e-12 of the
 result scale) where the arithmetic allows; fp32 cases 2e-5 of the result scale.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -560,3 +562,82 @@ def test_reference_curvature_pin(golden_tables):
     t = golden_tables
     surf = Spline(2, 3, [3, 4], [4, 5], [t["surface_knots0"], t["surface_knots1"]], t["surface_coefs"])
     assert abs(surf.curvature([0.25, 0.5]) - 1.024) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------
+# SplineBlock evaluation path (reference bspy/spline_block.py:179-247)
+# ---------------------------------------------------------------------------------------------
+def _block_oracle(c, kind, wrt=None, m=None):
+    pts = [p[:m] for p in c.points]
+    n = len(pts[0])
+    out = np.zeros((c.nDep, c.nInd, n) if kind == "jacobian" else (c.nDep, n))
+    r0 = 0
+    for row in c.rows:
+        k = row[0][1][1]
+        for imap, (nind, ndep, order, ncoef, knots, coefs) in row:
+            sub = [pts[i] for i in imap]
+            if kind == "jacobian":
+                j, _ = oracle.c_jacobian(order, ncoef, knots, coefs.astype(np.float64), sub)
+                out[r0:r0 + k, imap] += j
+            else:
+                w = [0] * nind if wrt is None else [wrt[i] for i in imap]
+                v, _ = oracle.c_evaluate(order, ncoef, knots, coefs.astype(np.float64), w, sub)
+                out[r0:r0 + k] += v
+        r0 += k
+    return out
+
+
+@pytest.mark.parametrize("case", cases.block_cases(), ids=lambda c: c.name)
+def test_spline_block_against_reference(case):
+    torch = pytest.importorskip("torch")
+    c = case
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "block.npz"))
+    blk = bspy_amd.SplineBlock([[(imap, Spline(*d)) for (imap, d) in row] for row in c.rows])
+    f32 = "f32" in c.name
+    tol = 2e-5 if f32 else 1e-12
+    m = g[f"{c.name}/evaluate"].shape[1]
+    pts = np.array([p[:m] for p in c.points])
+    # the reference's single-point API, on a few points (every call is a launch per spline)
+    for i in (0, 1, m - 1):
+        v = blk.evaluate(pts[:, i])
+        assert v.shape == (c.nDep,) and str(v.dtype) == str(g[f"{c.name}/dtype"])
+        ref = g[f"{c.name}/evaluate"][:, i]
+        assert np.abs(v - ref).max() <= tol * max(1.0, np.abs(ref).max())
+        assert np.array_equal(blk(pts[:, i]), v)
+        j = blk.jacobian(pts[:, i])
+        ref = g[f"{c.name}/jacobian"][:, :, i]
+        assert j.shape == (c.nDep, c.nInd) and np.abs(j - ref).max() <= 10 * tol * max(1.0, np.abs(ref).max())
+        w = c.wrts[-1]
+        ref = g[f"{c.name}/wrt_" + "_".join(map(str, w))][:, i]
+        assert np.abs(blk.derivative(w, pts[:, i]) - ref).max() <= 100 * tol * max(1.0, np.abs(ref).max())
+    # batched: goldens on the first m points, the oracle composition on the whole batch
+    full = blk.evaluate(c.points)
+    assert full.shape == (c.nDep, len(c.points[0]))
+    ref = g[f"{c.name}/evaluate"]
+    assert np.abs(full[:, :m] - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    orc = _block_oracle(c, "evaluate")
+    assert np.abs(full - orc).max() <= tol * max(1.0, np.abs(orc).max())
+    for w in c.wrts:
+        got = blk.derivative(w, c.points)
+        ref = g[f"{c.name}/wrt_" + "_".join(map(str, w))]
+        assert np.abs(got[:, :m] - ref).max() <= 100 * tol * max(1.0, np.abs(ref).max())
+        orc = _block_oracle(c, "evaluate", w)
+        assert np.abs(got - orc).max() <= 100 * tol * max(1.0, np.abs(orc).max())
+    jac = blk.jacobian(c.points)
+    ref = g[f"{c.name}/jacobian"]
+    assert jac.shape == (c.nDep, c.nInd, len(c.points[0]))
+    assert np.abs(jac[:, :, :m] - ref).max() <= 10 * tol * max(1.0, np.abs(ref).max())
+    orc = _block_oracle(c, "jacobian")
+    assert np.abs(jac - orc).max() <= 10 * tol * max(1.0, np.abs(orc).max())
+    # CUDA tensors in -> tensors out, same numbers; broadcasting shapes are kept
+    dev = [torch.as_tensor(p, device="cuda") for p in c.points]
+    td = blk.evaluate(dev)
+    assert td.is_cuda and np.array_equal(td.cpu().numpy(), full)
+    assert np.array_equal(blk.jacobian(dev).cpu().numpy(), jac)
+    two = blk.evaluate([p[:6].reshape(2, 3) for p in c.points])
+    assert two.shape == (c.nDep, 2, 3) and np.array_equal(two.reshape(c.nDep, 6), full[:, :6])
+    # out-of-domain point: the reference's message names the mapped parameters of the failing spline
+    bad = [p.copy() for p in c.points]
+    bad[0][5] = 1e3
+    with pytest.raises(ValueError, match="Spline evaluation outside domain"):
+        blk.evaluate(bad)

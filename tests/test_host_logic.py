@@ -322,3 +322,66 @@ def test_lds_hazard_checker_follows_control_flow():
 \ts_cbranch_vccnz .LBB0_1
 """
     assert _hazards(drained) == []
+
+
+# ---------------------------------------------------------------------------------------------
+# SplineBlock (reference bspy/spline_block.py): constructor semantics and the oracle restatement of
+# its evaluation path against goldens recorded from the reference (tests/golden/block.npz)
+# ---------------------------------------------------------------------------------------------
+def _block_oracle(c, kind, wrt=None, m=None):
+    """rows of the block = sums of the oracle's batched evaluations on the mapped variables"""
+    import oracle
+    pts = [p[:m] for p in c.points]
+    n = len(pts[0])
+    out = np.zeros((c.nDep, c.nInd, n) if kind == "jacobian" else (c.nDep, n))
+    r0 = 0
+    for row in c.rows:
+        k = row[0][1][1]
+        for imap, (nind, ndep, order, ncoef, knots, coefs) in row:
+            sub = [pts[i] for i in imap]
+            if kind == "jacobian":
+                j, bad = oracle.c_jacobian(order, ncoef, knots, coefs.astype(np.float64), sub)
+                out[r0:r0 + k, imap] += j
+            else:
+                w = [0] * nind if wrt is None else [wrt[i] for i in imap]
+                v, bad = oracle.c_evaluate(order, ncoef, knots, coefs.astype(np.float64), w, sub)
+                out[r0:r0 + k] += v
+            assert bad == -1
+        r0 += k
+    return out
+
+
+def test_spline_block_oracle_matches_reference_goldens():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "block.npz"))
+    for c in cases.block_cases():
+        m = g[f"{c.name}/evaluate"].shape[1]
+        assert tuple(g[f"{c.name}/nInd_nDep"]) == (c.nInd, c.nDep)
+        ref = g[f"{c.name}/evaluate"]
+        tol = 1e-5 if "f32" in c.name else 1e-12
+        assert np.abs(_block_oracle(c, "evaluate", m=m) - ref).max() <= tol * max(1.0, np.abs(ref).max())
+        ref = g[f"{c.name}/jacobian"]
+        assert np.abs(_block_oracle(c, "jacobian", m=m) - ref).max() <= tol * 10 * max(1.0, np.abs(ref).max())
+        for w in c.wrts:
+            ref = g[f"{c.name}/wrt_" + "_".join(map(str, w))]
+            assert np.abs(_block_oracle(c, "evaluate", w, m=m) - ref).max() <= tol * 100 * max(1.0, np.abs(ref).max())
+
+
+def test_spline_block_constructor_semantics():
+    from bspy_amd import Spline, SplineBlock
+    c = cases.block_cases()[1]
+    rows = [[(imap, Spline(*d)) for (imap, d) in row] for row in c.rows]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "block.npz"))
+    b = SplineBlock(rows)
+    assert (b.nInd, b.nDep, b.size) == (c.nInd, c.nDep, 3)
+    assert np.array_equal(b.domain(), g[f"{c.name}/domain"])
+    # a bare spline and a bare row are promoted (reference spline_block.py:55-58)
+    s = rows[0][0][1]
+    assert SplineBlock(s).nInd == s.nInd and SplineBlock([s]).nDep == s.nDep
+    with pytest.raises(ValueError, match="All splines in the same row must have the same nDep"):
+        SplineBlock([[rows[0][0], ([0, 1], rows[1][0][1].__class__(2, 1, (2, 2), (3, 3), [np.array([0., 0, .5, 1, 1]), np.array([0., 0, 1, 2, 2])], np.zeros((1, 3, 3))))]])
+    with pytest.raises(ValueError, match="Multiple splines in the same row map to independent variable 3"):
+        SplineBlock([[rows[0][0], ([3, 0], rows[0][1][1])]])
+    with pytest.raises(ValueError, match="Domains of independent variables must match"):
+        SplineBlock([[rows[0][0]], [([3, 2], rows[0][1][1])]])
+    with pytest.raises(ValueError, match="Block is missing independent variable 0"):
+        SplineBlock([[([1, 2], rows[0][1][1])]])
