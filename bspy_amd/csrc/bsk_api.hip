@@ -13,6 +13,7 @@
 #include "bsk_stream.hpp"
 #include "bsk_rowrot.hpp"
 #include "bsk_gather.hpp"
+#include "bsk_binned.hpp"
 
 using namespace bsk;
 
@@ -73,11 +74,12 @@ struct bsk_spline_s {
     void *coef = nullptr;    // device coefficients
     void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
     unsigned *lut = nullptr; // device span-search bucket tables
-    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot
+    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot, 7 no cell-order evaluation, 6 cell order without LDS row bundles
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
     DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
+    DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
 };
 
 template <typename T>
@@ -342,6 +344,7 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->in_ws.release();
     s->out_ws.release();
     s->aux_ws.release();
+    s->bin_ws.release();
     delete s;
     return BSK_OK;
 }
@@ -605,6 +608,108 @@ static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long lo
     return BSK_OK;
 }
 
+// Cell-order evaluation of large batches on L2-resident tables (bsk_binned.hpp).  Returns
+// BSK_ERR_UNSUPPORTED when it does not apply (the caller then gathers in batch order).
+constexpr long long BIN_MIN_POINTS = 1 << 18;
+#ifndef BIN_CHUNK_POINTS
+#define BIN_CHUNK_POINTS 8192
+#endif
+
+template <typename T, int NIND, int O>
+static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                     const Wrt &w, hipStream_t st)
+{
+    if constexpr (NIND < 2) {
+        return BSK_ERR_UNSUPPORTED;
+    } else {
+        if (n < BIN_MIN_POINTS || n > 0xffffffffll || !s->coef_aos || s->variant == 7 || s->nDep > 4) return BSK_ERR_UNSUPPORTED;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return BSK_ERR_UNSUPPORTED;                       // the workspace may have to be (re)allocated
+        }
+        const Desc<T> &d = desc_of<T>(s);
+        BinPlan bp;
+        const int s0 = s->ncoef[0] - O + 1, s1 = s->ncoef[1] - O + 1;
+        bp.sh0 = bp.sh1 = 0;
+        auto cells_of = [&](int sh0, int sh1) { return (((s0 - 1) >> sh0) + 1) * (((s1 - 1) >> sh1) + 1); };
+        while (cells_of(bp.sh0, bp.sh1) > BIN_MAX_CELLS) {
+            if ((s0 >> bp.sh0) >= (s1 >> bp.sh1)) ++bp.sh0; else ++bp.sh1;
+        }
+        bp.n1 = ((s1 - 1) >> bp.sh1) + 1;
+        bp.cells = cells_of(bp.sh0, bp.sh1);
+        bp.chunks = (int)std::max<long long>(1, std::min<long long>(BIN_MAX_CHUNKS, (n + BIN_CHUNK_POINTS - 1) / BIN_CHUNK_POINTS));
+        bp.chunk = (n + bp.chunks - 1) / bp.chunks;
+        const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
+        const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)bp.cells;
+        if (lds_count > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
+
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_cell = 0, o_slot = o_cell + up(2 * (size_t)n), o_rec = o_slot + up(4 * (size_t)n);
+        const size_t o_tmp = o_rec + up(sizeof(BinRec<T, NIND>) * (size_t)n);
+        size_t o_M = 0, o_tot = 0, o_start = 0, total = 0;
+        auto layout = [&](size_t out_bytes) {
+            o_M = o_tmp + up(out_bytes * (size_t)n);
+            o_tot = o_M + up(4 * (size_t)bp.cells * bp.chunks);
+            o_start = o_tot + up(4 * (size_t)bp.cells);
+            total = o_start + up(4 * (size_t)bp.cells);
+        };
+        const T *tab = static_cast<const T *>(s->tab);
+        const T *aos = static_cast<const T *>(s->coef_aos);
+        const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
+        // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
+        const size_t rows_b = (size_t)((1 << bp.sh0) + O - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + O - 1) : 1);
+        const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
+        const bool bundle_ok = s->variant != 6 && tab_b + bundle_b <= s->lds_max / 2;
+#define BINNED_ND(ND)                                                                                                    \
+    case ND: {                                                                                                           \
+        layout(sizeof(BinOut<T, ND>));                                                                                   \
+        HIPCHK(s->bin_ws.reserve(total));                                                                                \
+        char *ws = static_cast<char *>(s->bin_ws.p);                                                                     \
+        unsigned short *cell = reinterpret_cast<unsigned short *>(ws + o_cell);                                          \
+        unsigned *slot = reinterpret_cast<unsigned *>(ws + o_slot);                                                      \
+        BinRec<T, NIND> *rec = reinterpret_cast<BinRec<T, NIND> *>(ws + o_rec);                                          \
+        BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
+        unsigned *M = reinterpret_cast<unsigned *>(ws + o_M);                                                            \
+        unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
+        unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
+        HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
+        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(BIN_BLOCK), lds_count, st, d, bp, tab, prm, n, \
+                           cell, M, s->bad);                                                                             \
+        hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
+        hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
+        hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(BIN_BLOCK), sizeof(unsigned) * (size_t)bp.cells, \
+                           st, bp, prm, n, cell, M, start, rec, slot);                                                   \
+        if (bundle_ok) {                                                                                                 \
+            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND>, tab_b + bundle_b));                                        \
+            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d, bp,   \
+                               tab, aos, start, rec, n, tmp, w);                                                         \
+        } else {                                                                                                         \
+            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND>, tab_b));                                                       \
+            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos, rec, n,    \
+                               tmp, w);                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(egrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
+    } break;
+        switch (s->nDep) {
+            BINNED_ND(1) BINNED_ND(2) BINNED_ND(3) BINNED_ND(4)
+            default: return BSK_ERR_UNSUPPORTED;
+        }
+#undef BINNED_ND
+        HIPCHK(hipGetLastError());
+        return BSK_OK;
+    }
+}
+
+template <typename T, int NIND, int O>
+static bsk_status gather_or_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                   const Wrt &w, hipStream_t st)
+{
+    const bsk_status r = launch_eval_binned<T, NIND, O>(s, prm, n, out, ostride, w, st);
+    if (r != BSK_ERR_UNSUPPORTED) return r;
+    return launch_eval_gather<T, NIND, O>(s, prm, n, out, ostride, w, st);
+}
+
 // Fast-path coverage: nInd 1..3, one common order 1..6.
 static bool has_fixed_path(bsk_spline s)
 {
@@ -667,7 +772,7 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         }
     }
     if (has_fixed_path(s) && s->coef_aos && s->variant != 1) {
-#define CALL_GATHER(NIND, O) launch_eval_gather<T, NIND, O>(s, prm, n, out, ostride, w, st)
+#define CALL_GATHER(NIND, O) gather_or_binned<T, NIND, O>(s, prm, n, out, ostride, w, st)
         if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_GATHER) }
         else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_GATHER) }
         else { BSK_ORDER_SWITCH(3, CALL_GATHER) }

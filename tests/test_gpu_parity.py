@@ -396,6 +396,50 @@ def test_kernel_variants(variant, golden_parity, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [
+    (2, 2, (4, 4), (200, 150), np.float64),       # 480 KB surface table, 29 k cells -> coarsened to <= 8192
+    (2, 4, (3, 3), (300, 300), np.float32),       # nDep 4 fp32: 16-byte records and results
+    (3, 1, (3, 3, 3), (50, 40, 30), np.float64),  # fp64 volume: 32-byte records
+    (3, 4, (5, 5, 5), (40, 40, 40), np.float32),  # cfg5 shape
+    (3, 3, (4, 4, 4), (36, 30, 44), np.float64),  # nDep 3 fp64
+])
+def test_large_batches_in_cell_order(shape, monkeypatch):
+    """Batches of >= 2^18 points on L2-resident tables are counting-sorted by the cell of the first
+    two variables and evaluated in cell order (bsk_binned.hpp).  Same arithmetic as the gather
+    kernel: results are bitwise those of BSK_VARIANT=7 (cell order off), for every derivative, and
+    match the oracle; the first out-of-domain point is still reported by its batch index."""
+    nind, ndep, order, ncoef, dt = shape
+    rng = np.random.default_rng(77)
+    knots = [cases.nonuniform_knots(rng, o, c, dt, -1.0, 2.0) for o, c in zip(order, ncoef)]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+    n = 300_007
+    pts = [(-1.0 + 3.0 * rng.random(n)).astype(dt) for _ in range(nind)]
+    # clustered points too: one cell takes most of the batch
+    pts[0][: n // 2] = dt(0.123)
+    pts[1][: n // 3] = dt(1.5)
+    tol = 2e-5 if dt == np.float32 else 1e-12
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    monkeypatch.setenv("BSK_VARIANT", "7")
+    plain = DeviceSpline(order, ncoef, knots, coefs, dt)
+    monkeypatch.setenv("BSK_VARIANT", "6")                   # cell order, windows through L1 instead of LDS bundles
+    nolds = DeviceSpline(order, ncoef, knots, coefs, dt)
+    sample = rng.choice(n, 20_000, replace=False)
+    for w in ([0] * nind, [1] + [0] * (nind - 1), [0] * (nind - 1) + [2]):
+        out = t.evaluate(pts, w)
+        assert np.array_equal(out, plain.evaluate(pts, w)), (shape, w)
+        assert np.array_equal(out, nolds.evaluate(pts, w)), (shape, w)
+        orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, [p[sample] for p in pts])
+        assert bad == -1
+        assert np.abs(out[:, sample] - orc).max() <= tol * _scale(orc), (shape, w)
+    assert np.array_equal(out, t.evaluate(pts, w))                       # second run: same bits
+    bad = [p.copy() for p in pts]
+    bad[1][123_456] = dt(7.0)
+    bad[0][250_000] = dt(-9.0)
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 123_456
+
+
+@pytest.mark.parametrize("shape", [
     (1, 3, (4,), (50_000,), np.float64),          # 1.2 MB curve table
     (2, 2, (4, 4), (200, 150), np.float64),       # 480 KB surface table
     (2, 4, (3, 3), (300, 300), np.float32),       # 1.4 MB, nDep 4 (one 16-byte load per control point)
