@@ -16,10 +16,26 @@ There is no CPU compute path: without the shared library every call raises.
 from . import _native
 from ._native import BskError, DomainError, NativeLibraryError
 from .device_spline import DeviceSpline, bspline_values_batch, get_device, set_device
+from .device_spline import tessellate as tessellate_tables
 from .spline import Spline
 from .collocation import collocation_matrix
 from .spline_block import SplineBlock
 
-__all__ = ["Spline", "SplineBlock", "DeviceSpline", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
+
+def tessellate(splines, u, v, normals=True, normalize=True):
+    """Positions (and unit normals) of a batch of ``Spline`` surface patches on the grid ``u x v`` in one
+    launch: ``(len(splines), 3, len(u), len(v))`` arrays (NumPy in -> NumPy out, CUDA tensors in -> tensors
+    out).  The patches must share orders, nCoef and knots (e.g. the 32 patches of the Utah teapot); each
+    patch's ``metadata['negateNormal']`` must agree.  See ``bspy_amd.device_spline.tessellate``."""
+    from . import _spline_evaluation as _se
+    splines = list(splines)
+    neg = {bool(getattr(s, 'metadata', {}).get('negateNormal', False)) for s in splines}
+    if len(neg) > 1:
+        raise ValueError('the patches of a batch must agree on negateNormal')
+    dev = u.device.index if type(u).__module__.split('.')[0] == 'torch' else None
+    tables = [_se.device_tables(s, dev) for s in splines]
+    return tessellate_tables(tables, (u, v), normals=normals, normalize=normalize, negate=neg.pop() if neg else False)
+
+__all__ = ["Spline", "SplineBlock", "DeviceSpline", "tessellate", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
            "BskError", "DomainError", "NativeLibraryError"]
 __version__ = "0.1.0"

@@ -23,8 +23,8 @@ BSK_MAX_NIND, BSK_MAX_ORDER = 8, 16
 SYMBOLS = (
     "bsk_version", "bsk_last_error", "bsk_device_count",
     "bsk_spline_create", "bsk_spline_update", "bsk_spline_destroy",
-    "bsk_evaluate", "bsk_jacobian", "bsk_normal", "bsk_curvature", "bsk_evaluate_grid", "bsk_domain_status",
-    "bsk_bspline_values",
+    "bsk_evaluate", "bsk_jacobian", "bsk_normal", "bsk_curvature", "bsk_evaluate_grid", "bsk_tessellate",
+    "bsk_domain_status", "bsk_bspline_values",
 )
 
 
@@ -91,6 +91,8 @@ def lib():
     L.bsk_normal.argtypes = [_vp, _vpp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _i64p]
     L.bsk_curvature.argtypes = [_vp, _vpp, _i64, ctypes.c_int, _vp, _vp, _i64p]
     L.bsk_evaluate_grid.argtypes = [_vp, _ip, _vpp, _i64p, ctypes.c_int, _vp, _vp, _i64p]
+    L.bsk_tessellate.argtypes = [_vpp, ctypes.c_int, _vpp, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                 _i64p]
     L.bsk_domain_status.argtypes = [_vp, _vp, _i64p]
     L.bsk_bspline_values.argtypes = [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _i64,
                                      ctypes.c_int, ctypes.c_int, _i32p, _i32p, _vp]

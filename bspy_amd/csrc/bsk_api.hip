@@ -80,6 +80,7 @@ struct bsk_spline_s {
     size_t lds_max = 160 * 1024;
     DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
     DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
+    std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
 };
 
 template <typename T>
@@ -176,6 +177,8 @@ static bsk_status upload_tables(bsk_spline s, const void *const *knots, const vo
     if ((int)lut.size() != td.lut_len) return fail(BSK_ERR_INVALID, "internal: bucket table size changed");
     HIPCHK(hipSetDevice(s->device));
     if (d.tab_len) HIPCHK(hipMemcpy(s->tab, tab.data(), sizeof(T) * tab.size(), hipMemcpyHostToDevice));
+    s->tab_host.assign(reinterpret_cast<const unsigned char *>(tab.data()),
+                       reinterpret_cast<const unsigned char *>(tab.data()) + sizeof(T) * tab.size());
     if (td.lut_len) HIPCHK(hipMemcpy(s->lut, lut.data(), sizeof(unsigned) * lut.size(), hipMemcpyHostToDevice));
     if (d.coef_len) HIPCHK(hipMemcpy(s->coef, coefs, sizeof(T) * (size_t)d.coef_len, hipMemcpyHostToDevice));
     if (s->coef_aos) {
@@ -1240,6 +1243,138 @@ extern "C" bsk_status bsk_evaluate_grid(bsk_spline s, const int *wrt, const void
     hipStream_t st = static_cast<hipStream_t>(stream);
     return s->dtype == BSK_F32 ? run_grid<float>(s, wrt, grid, ngrid, mem, out, st, first_bad)
                                : run_grid<double>(s, wrt, grid, ngrid, mem, out, st, first_bad);
+}
+
+// ------------------------------------------------------------------------------------
+// tessellation of a batch of patches (positions + normals), SURVEY 8f-2
+// ------------------------------------------------------------------------------------
+template <typename T>
+static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *const *grid, const int64_t *ngrid,
+                                 bsk_mem mem, int normalize, int negate, void *positions, void *normals, hipStream_t st,
+                                 int64_t *first_bad)
+{
+    bsk_spline s = sp[0];
+    const Desc<T> &d = desc_of<T>(s);
+    if (first_bad) *first_bad = -1;
+    GridDims g;
+    long long npar = 0, nrow = 0;
+    for (int iv = 0; iv < MAXI; ++iv) { g.n[iv] = 1; g.goff[iv] = 0; g.roff[iv] = 0; }
+    for (int iv = 0; iv < 2; ++iv) {
+        if (ngrid[iv] < 0) return fail(BSK_ERR_INVALID, "negative grid size");
+        g.n[iv] = ngrid[iv];
+        g.goff[iv] = npar;
+        g.roff[iv] = nrow;
+        npar += ngrid[iv];
+        nrow += ngrid[iv] * s->order[iv];
+    }
+    const long long total = g.n[0] * g.n[1];
+    if (total == 0 || count == 0) return BSK_OK;
+
+    // aux workspace of the first patch: [params (host mode)] [value rows] [derivative rows] [ix] [outside]
+    const size_t par_b = mem == BSK_HOST ? ((sizeof(T) * (size_t)npar + 15) & ~(size_t)15) : 0;
+    const size_t row_b = (sizeof(T) * (size_t)nrow + 15) & ~(size_t)15;
+    const size_t ix_b = (sizeof(int) * (size_t)npar + 15) & ~(size_t)15;
+    HIPCHK(s->aux_ws.reserve(par_b + 2 * row_b + 2 * ix_b + 2 * (size_t)npar + 32));
+    char *base = static_cast<char *>(s->aux_ws.p);
+    T *dpar = reinterpret_cast<T *>(base);
+    T *rows = reinterpret_cast<T *>(base + par_b);
+    T *drows = reinterpret_cast<T *>(base + par_b + row_b);
+    int *ixs = reinterpret_cast<int *>(base + par_b + 2 * row_b);
+    int *ixs2 = reinterpret_cast<int *>(base + par_b + 2 * row_b + ix_b);
+    unsigned char *outside = reinterpret_cast<unsigned char *>(base + par_b + 2 * row_b + 2 * ix_b);
+    unsigned char *outside2 = outside + ((npar + 15) & ~15ll);
+
+    GridAxes<T> ax;
+    long long nmax = 1;
+    for (int iv = 0; iv < MAXI; ++iv) { ax.u[iv] = nullptr; ax.wrt[iv] = 0; }
+    for (int iv = 0; iv < 2; ++iv) {
+        const T *u = static_cast<const T *>(grid[iv]);
+        if (mem == BSK_HOST) {
+            HIPCHK(hipMemcpyAsync(dpar + g.goff[iv], u, sizeof(T) * (size_t)ngrid[iv], hipMemcpyHostToDevice, st));
+            u = dpar + g.goff[iv];
+        }
+        ax.u[iv] = u;
+        nmax = std::max<long long>(nmax, ngrid[iv]);
+    }
+    const T *tab = static_cast<const T *>(s->tab);
+    hipLaunchKernelGGL((basis_rows_grid<T>), dim3((unsigned)((nmax + 255) / 256), 2u), dim3(256), 0, st, d, tab, ax, g, ixs,
+                       rows, outside);
+    if (normals) {
+        ax.wrt[0] = ax.wrt[1] = 1;                            // first-derivative rows of both variables
+        hipLaunchKernelGGL((basis_rows_grid<T>), dim3((unsigned)((nmax + 255) / 256), 2u), dim3(256), 0, st, d, tab, ax, g,
+                           ixs2, drows, outside2);
+    }
+    HIPCHK(hipGetLastError());
+
+    T *dpos = static_cast<T *>(positions), *dnrm = static_cast<T *>(normals);
+    const size_t plane = sizeof(T) * (size_t)total * 3 * (size_t)count;
+    if (mem == BSK_HOST) {
+        HIPCHK(s->out_ws.reserve(plane * (normals ? 2 : 1)));
+        dpos = static_cast<T *>(s->out_ws.p);
+        dnrm = normals ? dpos + (size_t)total * 3 * (size_t)count : nullptr;
+    }
+    constexpr long long VEC = 16 / (long long)sizeof(T);
+    const int vec_ok = (g.n[1] % VEC == 0) && ((reinterpret_cast<uintptr_t>(dpos) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(dnrm) & 15) == 0) ? 1 : 0;
+    const size_t lds = sizeof(T) * 3 * (size_t)s->ncoef[1] * 2;
+    for (int p0 = 0; p0 < count; p0 += TESS_MAX_PATCHES) {
+        const int np = std::min(TESS_MAX_PATCHES, count - p0);
+        PatchCoefs<T> pc;
+        for (int i = 0; i < TESS_MAX_PATCHES; ++i) pc.c[i] = i < np ? static_cast<const T *>(sp[p0 + i]->coef) : nullptr;
+        const int gx = (int)std::max<long long>(1, std::min<long long>(g.n[0], std::max<long long>(1, (long long)s->num_cu * 8 / np)));
+        T *pp = dpos + (size_t)p0 * 3 * (size_t)total;
+        T *pn = dnrm ? dnrm + (size_t)p0 * 3 * (size_t)total : nullptr;
+#define TESS(O)                                                                                                        \
+    case O:                                                                                                            \
+        if (normals)                                                                                                   \
+            hipLaunchKernelGGL((tess_rows<T, O, true>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows, drows,  \
+                               outside, pp, pn, s->bad, vec_ok, normalize, negate);                                    \
+        else                                                                                                           \
+            hipLaunchKernelGGL((tess_rows<T, O, false>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows, rows,  \
+                               outside, pp, pn, s->bad, vec_ok, normalize, negate);                                    \
+        break;
+        switch (s->order[0]) {
+            TESS(1) TESS(2) TESS(3) TESS(4) TESS(5) TESS(6)
+            default: return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: orders 1..6");
+        }
+#undef TESS
+    }
+    HIPCHK(hipGetLastError());
+    if (mem == BSK_HOST) {
+        HIPCHK(hipMemcpyAsync(positions, dpos, plane, hipMemcpyDeviceToHost, st));
+        if (normals) HIPCHK(hipMemcpyAsync(normals, dnrm, plane, hipMemcpyDeviceToHost, st));
+        return read_bad(s, st, first_bad);
+    }
+    return BSK_OK;
+}
+
+extern "C" bsk_status bsk_tessellate(const bsk_spline *splines, int count, const void *const *grid, const int64_t *ngrid,
+                                     bsk_mem mem, int normalize, int negate, void *positions, void *normals, void *stream,
+                                     int64_t *first_bad)
+{
+    if (count < 0) return fail(BSK_ERR_INVALID, "negative patch count");
+    if (count == 0) return BSK_OK;
+    if (!splines || !grid || !ngrid || !positions) return fail(BSK_ERR_INVALID, "NULL argument");
+    bsk_spline s = splines[0];
+    if (!s) return fail(BSK_ERR_INVALID, "NULL handle");
+    if (s->nInd != 2 || s->nDep != 3) return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: surfaces in 3-D (nInd 2, nDep 3)");
+    if (!s->same_order || s->order[0] > 6 || sizeof(double) * 6 * (size_t)s->ncoef[1] > 60 * 1024)
+        return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: one common order <= 6, nCoef[1] <= 1280");
+    for (int i = 1; i < count; ++i) {
+        bsk_spline t = splines[i];
+        if (!t) return fail(BSK_ERR_INVALID, "NULL handle");
+        if (t->dtype != s->dtype || t->device != s->device || t->nInd != 2 || t->nDep != 3 || t->order[0] != s->order[0] ||
+            t->order[1] != s->order[1] || t->ncoef[0] != s->ncoef[0] || t->ncoef[1] != s->ncoef[1] ||
+            t->tab_host != s->tab_host)
+            return fail(BSK_ERR_INVALID, "bsk_tessellate: the patches of a batch must share dtype, device, orders, nCoef and knots");
+    }
+    for (int iv = 0; iv < 2; ++iv)
+        if (!grid[iv] && ngrid[iv] > 0) return fail(BSK_ERR_INVALID, "NULL grid pointer");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return s->dtype == BSK_F32
+               ? run_tessellate<float>(splines, count, grid, ngrid, mem, normalize, negate, positions, normals, st, first_bad)
+               : run_tessellate<double>(splines, count, grid, ngrid, mem, normalize, negate, positions, normals, st, first_bad);
 }
 
 // ------------------------------------------------------------------------------------

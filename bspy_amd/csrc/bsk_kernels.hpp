@@ -443,6 +443,142 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
 }
 
 // ---------------------------------------------------------------------------------
+// tess_rows: tessellation of a BATCH of surface patches in 3-D on one parameter grid - positions
+// and (NORMALS) normals of every patch in one launch (the compute-side counterpart
+// of the reference's GLSL tessellation shaders, bspy/splineOpenGLFrame.py:671-714; per patch it
+// replaces s(u[:, None], v[None, :]) and Spline.normal at every grid point,
+// bspy/_spline_evaluation.py:215-246).  The patches share orders, nCoef and knots (the 32 Bezier
+// patches of the Utah teapot), so the basis rows of the grid lines are computed once; grid_rows'
+// row factorisation is applied per (patch, grid row): rowc = sum_a b0[a] C[.., a, :] and, for the
+// normals, drowc = sum_a b0'[a] C[.., a, :]; a point then needs O multiply-adds per output:
+//   position = rowc . b1,   S_u = drowc . b1,   S_v = rowc . b1',   normal = S_u x S_v.
+// blockIdx.y = patch.  pos / nrm [((patch * 3 + dep) * n0 + i0) * n1 + i1]
+// ---------------------------------------------------------------------------------
+constexpr int TESS_MAX_PATCHES = 64;
+template <typename T>
+struct PatchCoefs {
+    const T *c[TESS_MAX_PATCHES];
+};
+
+template <typename T>
+__device__ __forceinline__ void tess_normal(const T (&su)[3], const T (&sv)[3], int normalize, int negate, T (&n)[3])
+{
+    // cofactors of the 3 x 2 tangent space, as in jac_rowrot<.., NORMAL>
+    T nx = su[1] * sv[2] - sv[1] * su[2];
+    T ny = -(su[0] * sv[2] - sv[0] * su[2]);
+    T nz = su[0] * sv[1] - sv[0] * su[1];
+    if (negate) { nx = -nx; ny = -ny; nz = -nz; }
+    if (normalize) {
+        const T len = sqrt(nx * nx + ny * ny + nz * nz);
+        nx = nx / len; ny = ny / len; nz = nz / len;
+    }
+    n[0] = nx; n[1] = ny; n[2] = nz;
+}
+
+template <typename T, int O, bool NORMALS>
+__global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoefs<T> pc, const GridDims g,
+                                                 const int *__restrict__ ixs, const T *__restrict__ rows,
+                                                 const T *__restrict__ drows, const unsigned char *__restrict__ outside,
+                                                 T *__restrict__ pos, T *__restrict__ nrm, unsigned long long *bad,
+                                                 const int vec_ok, const int normalize, const int negate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    const int nc1 = d.ncoef[1], s0 = d.cstride[1];
+    T *rowc = reinterpret_cast<T *>(smem_g);                  // [3][nCoef1]
+    T *drowc = rowc + 3 * nc1;                                // [3][nCoef1]  (NORMALS)
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const long long n1 = g.n[1], total = g.n[0] * g.n[1];
+    const T *__restrict__ gcoef = pc.c[blockIdx.y];
+    T *ppos = pos + (long long)blockIdx.y * 3 * total;
+    T *pnrm = NORMALS ? nrm + (long long)blockIdx.y * 3 * total : nullptr;
+    for (long long i0 = blockIdx.x; i0 < g.n[0]; i0 += gridDim.x) {
+        const int ix0 = ixs[g.goff[0] + i0];
+        const bool bad0 = outside[g.goff[0] + i0] != 0;
+        T b0[O], db0[O];
+#pragma unroll
+        for (int a = 0; a < O; ++a) {
+            b0[a] = rows[g.roff[0] + i0 * O + a];
+            db0[a] = NORMALS ? drows[g.roff[0] + i0 * O + a] : T(0);
+        }
+        __syncthreads();                                       // the previous row's readers are done
+        for (int e = threadIdx.x; e < 3 * nc1; e += blockDim.x) {
+            const int dep = e / nc1, c = e - dep * nc1;
+            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - O) * s0 + c;
+            T acc = T(0), dacc = T(0);
+#pragma unroll
+            for (int a = 0; a < O; ++a) {
+                const T cv = col[a * s0];
+                acc += b0[a] * cv;
+                dacc += db0[a] * cv;
+            }
+            rowc[e] = acc;
+            if constexpr (NORMALS) drowc[e] = dacc;
+        }
+        __syncthreads();
+        const long long step = vec_ok ? VEC : 1;
+        for (long long c0 = (long long)threadIdx.x * step; c0 < n1; c0 += (long long)blockDim.x * step) {
+            T P[3][VEC], Nn[3][VEC];
+            const int nv = vec_ok ? VEC : 1;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (v < nv) {
+                    const int ix1 = ixs[g.goff[1] + c0 + v] - O;
+                    T b1[O], db1[O];
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        b1[k] = rows[g.roff[1] + (c0 + v) * O + k];
+                        db1[k] = NORMALS ? drows[g.roff[1] + (c0 + v) * O + k] : T(0);
+                    }
+                    if (blockIdx.y == 0 && (bad0 | (outside[g.goff[1] + c0 + v] != 0))) record_bad(bad, i0 * n1 + c0 + v);
+                    T su[3], sv[3];
+#pragma unroll
+                    for (int dep = 0; dep < 3; ++dep) {
+                        const T *rc = rowc + dep * nc1 + ix1;
+                        const T *drc = drowc + dep * nc1 + ix1;
+                        T p = T(0), u_ = T(0), v_ = T(0);
+#pragma unroll
+                        for (int k = 0; k < O; ++k) {
+                            p += rc[k] * b1[k];
+                            if constexpr (NORMALS) { u_ += drc[k] * b1[k]; v_ += rc[k] * db1[k]; }
+                        }
+                        P[dep][v] = p; su[dep] = u_; sv[dep] = v_;
+                    }
+                    if constexpr (NORMALS) {
+                        T nn[3];
+                        tess_normal<T>(su, sv, normalize, negate, nn);
+                        Nn[0][v] = nn[0]; Nn[1][v] = nn[1]; Nn[2][v] = nn[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int dep = 0; dep < 3; ++dep) {
+                T *o = ppos + dep * total + i0 * n1 + c0;
+                if (vec_ok) {
+                    vec_t w;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) w[v] = P[dep][v];
+                    __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(o));
+                } else {
+                    __builtin_nontemporal_store(P[dep][0], o);
+                }
+                if constexpr (NORMALS) {
+                    T *q = pnrm + dep * total + i0 * n1 + c0;
+                    if (vec_ok) {
+                        vec_t w;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) w[v] = Nn[dep][v];
+                        __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(q));
+                    } else {
+                        __builtin_nontemporal_store(Nn[dep][0], q);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // normal from a batched jacobian (next row: reference bspy/_spline_evaluation.py:215-246).
 // |nInd - nDep| == 1, big = max(nInd, nDep) <= 4.  jac[(dep * nInd + j) * N + n] (the layout
 // bsk_jacobian writes); the tangent space is taken with its larger dimension first,

@@ -277,6 +277,59 @@ class DeviceSpline:
         nv.check(st, bad)
 
 
+def tessellate(patches, axes, normals=True, normalize=True, negate=False, out=None, check=True):
+    """Positions and normals of a BATCH of surface patches in 3-D on one parameter grid, one launch
+    for all patches (C ABI ``bsk_tessellate``).
+
+    patches : sequence of DeviceSpline with nInd 2, nDep 3 that share dtype, orders, nCoef and knots
+    axes    : (u, v) 1-D arrays.  NumPy arrays -> NumPy results; CUDA torch tensors -> the results
+              stay on the GPU (``out=(positions, normals)`` may pass preallocated tensors)
+    returns : positions ``(len(patches), 3, len(u), len(v))`` and, with ``normals``, the normals
+              (cross product of the partial derivatives; unit length when ``normalize``) in the same
+              shape.
+    """
+    patches = list(patches)
+    if not patches:
+        raise ValueError("tessellate needs at least one patch")
+    if len(axes) != 2:
+        raise ValueError(f"Incorrect number of parameter values: {len(axes)}")
+    first = patches[0]
+    handles = (ctypes.c_void_p * len(patches))(*[p._handle for p in patches])
+    bad = ctypes.c_int64(-1)
+    if any(_is_torch(a) for a in axes):
+        import torch
+        tdt = torch.float32 if first.dtype == np.float32 else torch.float64
+        gs = [a.to(tdt).contiguous().view(-1) for a in axes]
+        shape = (len(patches), 3, int(gs[0].numel()), int(gs[1].numel()))
+        pos, nrm = out if out is not None else (None, None)
+        if pos is None:
+            pos = torch.empty(shape, dtype=tdt, device=gs[0].device)
+        if normals and nrm is None:
+            nrm = torch.empty(shape, dtype=tdt, device=gs[0].device)
+        for t in (pos, nrm) if normals else (pos,):
+            if t.dtype != tdt or tuple(t.shape) != shape or not t.is_contiguous():
+                raise ValueError("out tensors must be contiguous (patches, 3, n_u, n_v) tensors of the patches' dtype")
+        ng = (ctypes.c_int64 * 2)(shape[2], shape[3])
+        st = nv.lib().bsk_tessellate(handles, len(patches), nv.ptr_array([g.data_ptr() for g in gs]), ng, nv.BSK_DEVICE,
+                                     int(bool(normalize)), int(bool(negate)), pos.data_ptr(),
+                                     nrm.data_ptr() if normals else None,
+                                     DeviceSpline._stream_ptr(torch, first.device), None)
+        nv.check(st)
+        if check:
+            first.domain_status()
+        return (pos, nrm) if normals else pos
+    gs = [np.ascontiguousarray(a, first.dtype).ravel() for a in axes]
+    shape = (len(patches), 3, gs[0].size, gs[1].size)
+    pos = np.empty(shape, first.dtype)
+    nrm = np.empty(shape, first.dtype) if normals else None
+    ng = (ctypes.c_int64 * 2)(shape[2], shape[3])
+    st = nv.lib().bsk_tessellate(handles, len(patches), nv.ptr_array([g.ctypes.data for g in gs]), ng, nv.BSK_HOST,
+                                 int(bool(normalize)), int(bool(negate)), pos.ctypes.data,
+                                 nrm.ctypes.data if normals else None, None, ctypes.byref(bad))
+    nv.check(st, bad)
+    return (pos, nrm) if normals else pos
+
+
 def bspline_values_batch(knots, order, u, derivative_order=0, taylor_coefs=False, knot=None, device=None):
     """Batched basis values: returns (ix int32 (N,), basis (N, order)) in the knots' dtype
     (float32 stays float32, everything else is computed in float64)."""

@@ -132,6 +132,24 @@ bsk_status bsk_evaluate_grid(bsk_spline s, const int *wrt, const void *const *gr
                              bsk_mem mem, void *out, void *stream, int64_t *first_bad);
 
 /*
+ * Tessellation of a BATCH of surface patches in 3-D on one parameter grid: positions and, optionally,
+ * normals of every patch from one launch (next row).
+ * Replaces: per patch the broadcast call s(u[:, None], v[None, :]) (bspy/spline.py:941-945) and
+ *   Spline.normal at every grid point (bspy/spline.py:1648-1682 -> bspy/_spline_evaluation.py:215-246);
+ *   it is the compute-side counterpart of the reference's GLSL tessellation shaders
+ *   (bspy/splineOpenGLFrame.py:671-714), e.g. for the 32 patches of examples/teapot.py.
+ *   splines    : count handles with nInd 2, nDep 3 that share dtype, device, orders, nCoef and knots
+ *   grid[iv]   : ngrid[iv] values of variable iv (the grid is shared by all patches)
+ *   positions  : count * 3 * n0 * n1 values, positions[((p * 3 + d) * n0 + i0) * n1 + i1]
+ *   normals    : NULL, or the same shape: cross product of the two partial derivatives
+ *                (normalize / negate as in bsk_normal)
+ *   first_bad  : flat index i0 * n1 + i1 of the first grid point outside the domain
+ */
+bsk_status bsk_tessellate(const bsk_spline *splines, int count, const void *const *grid, const int64_t *ngrid,
+                          bsk_mem mem, int normalize, int negate, void *positions, void *normals, void *stream,
+                          int64_t *first_bad);
+
+/*
  * Synchronise `stream` and report whether any BSK_DEVICE call on this handle since the
  * last bsk_domain_status() met an out-of-domain parameter (*first_bad = smallest such
  * index, else -1).  Resets the record.

@@ -178,6 +178,41 @@ def block_cases():
     return cs
 
 
+def teapot_patches(tables, which=None, dtype=np.float32):
+    """Control nets of the Utah teapot's bicubic Bezier patches as (order, nCoef, knots, coefs)
+    from the reference's data tables (tests/golden/reference_tables.npz: examples/teapot.py:4-346),
+    arranged like the reference example does (x, z, y -> nDep 0, 1, 2; examples/teapot.py:349-358)."""
+    V, P = tables["teapot_vertices"], tables["teapot_patch_index"]
+    knots = np.array((0, 0, 0, 0, 1, 1, 1, 1), dtype)
+    out = []
+    for pi in (range(len(P)) if which is None else which):
+        c = np.empty((3, 4, 4), dtype)
+        for i in range(4):
+            for j in range(4):
+                v = V[P[pi][4 * i + j] - 1]
+                c[0, i, j], c[1, i, j], c[2, i, j] = v[0], v[2], v[1]
+        out.append(((4, 4), (4, 4), [knots, knots], c))
+    return out
+
+
+def tess_cases():
+    """Tessellation batches: name -> (list of (order, nCoef, knots, coefs), u, v).
+    The teapot batch is built by the caller from reference_tables.npz (teapot_patches)."""
+    rng = np.random.default_rng(4242)
+    out = {}
+    # five order-3 x 3 patches on shared non-uniform knots, fp64, odd grid sizes
+    ku = nonuniform_knots(rng, 3, 6, np.float64, 0.0, 2.0)
+    kv = nonuniform_knots(rng, 3, 7, np.float64, -1.0, 1.0)
+    patches = [((3, 3), (6, 7), [ku, kv], rng.standard_normal((3, 6, 7))) for _ in range(5)]
+    out["o3_f64"] = (patches, np.linspace(0.0, 2.0, 11), np.linspace(-1.0, 1.0, 9))
+    # two order-5 patches, fp64, grid sizes divisible by the vector width
+    ku = clamped_uniform_knots(5, 9)
+    kv = clamped_uniform_knots(5, 8)
+    patches = [((5, 5), (9, 8), [ku, kv], rng.standard_normal((3, 9, 8))) for _ in range(2)]
+    out["o5_f64"] = (patches, np.linspace(0.0, 1.0, 6), np.linspace(0.0, 1.0, 8))
+    return out
+
+
 def basis_cases():
     """Direct bspline_values goldens: tuples
     (knots, order, u, derivativeOrder, taylorCoefs, explicit_knot_or_None)."""

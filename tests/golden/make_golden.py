@@ -229,8 +229,31 @@ def block_golden(bspy):
     return out
 
 
+def tess_golden(bspy):
+    """Positions and unit normals on a grid, per patch, from the reference: the broadcast call
+    s(u[:, None], v[None, :]) and Spline.normal at every grid point."""
+    out = {}
+    tables = np.load(os.path.join(HERE, "reference_tables.npz"))
+    batches = dict(cases.tess_cases())
+    batches["teapot_f32"] = (cases.teapot_patches(tables, which=(0, 5, 13, 31)), np.linspace(0, 1, 8, dtype=np.float32),
+                             np.linspace(0, 1, 12, dtype=np.float32))
+    for name, (patches, u, v) in batches.items():
+        pos, nrm = [], []
+        for (order, ncoef, knots, coefs) in patches:
+            s = bspy.Spline(2, 3, order, ncoef, knots, coefs)
+            pos.append(np.array(s(u[:, None], v[None, :]), np.float64))
+            nrm.append(np.array([[s.normal((ui, vj)) for vj in v] for ui in u], np.float64).transpose(2, 0, 1))
+        out[f"{name}/positions"] = np.array(pos)
+        out[f"{name}/normals"] = np.array(nrm)
+        print("tess", name, "done", flush=True)
+    return out
+
+
 def main():
     bspy = load_reference()
+    if "--only-tess" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "tess.npz"), **tess_golden(bspy))
+        return
     if "--only-block" in sys.argv:
         np.savez_compressed(os.path.join(HERE, "block.npz"), **block_golden(bspy))
         return
@@ -258,6 +281,7 @@ def main():
     with open(os.path.join(HERE, "api_semantics.json"), "w") as f:
         json.dump(api_semantics(bspy), f, indent=1)
     np.savez_compressed(os.path.join(HERE, "block.npz"), **block_golden(bspy))
+    np.savez_compressed(os.path.join(HERE, "tess.npz"), **tess_golden(bspy))
     print("golden fixtures written to", HERE)
 
 

@@ -385,3 +385,32 @@ def test_spline_block_constructor_semantics():
         SplineBlock([[rows[0][0]], [([3, 2], rows[0][1][1])]])
     with pytest.raises(ValueError, match="Block is missing independent variable 0"):
         SplineBlock([[([1, 2], rows[0][1][1])]])
+
+
+# ---------------------------------------------------------------------------------------------
+# tessellation goldens (tests/golden/tess.npz, recorded from the reference): the oracle's
+# evaluate / normal on the grid points must reproduce them
+# ---------------------------------------------------------------------------------------------
+def _tess_batches():
+    tables = np.load(os.path.join(ROOT, "tests", "golden", "reference_tables.npz"))
+    b = dict(cases.tess_cases())
+    b["teapot_f32"] = (cases.teapot_patches(tables, which=(0, 5, 13, 31)), np.linspace(0, 1, 8, dtype=np.float32),
+                       np.linspace(0, 1, 12, dtype=np.float32))
+    return b
+
+
+def test_tessellation_oracle_matches_reference_goldens():
+    import oracle
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tess.npz"))
+    for name, (patches, u, v) in _tess_batches().items():
+        uu, vv = [a.reshape(-1) for a in np.meshgrid(u, v, indexing="ij")]
+        tol = 2e-5 if "f32" in name else 1e-12
+        for p, (order, ncoef, knots, coefs) in enumerate(patches):
+            pos, _ = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [uu, vv])
+            ref = g[f"{name}/positions"][p].reshape(3, -1)
+            assert np.abs(pos - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, p)
+            nrm, _ = oracle.c_normal(order, ncoef, knots, coefs, [uu, vv], True, False)
+            ref = g[f"{name}/normals"][p].reshape(3, -1)
+            ok = np.isfinite(ref).all(axis=0) & np.isfinite(nrm).all(axis=0)
+            assert ok.sum() >= 0.8 * ok.size
+            assert np.abs(nrm[:, ok] - ref[:, ok]).max() <= (2e-3 if "f32" in name else 1e-9), (name, p)

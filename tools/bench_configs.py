@@ -52,6 +52,18 @@ res["cfg4_teapot_patch_grid2048"] = {"ms": round(s * 1e3, 4), "Mevals_s": round(
                                       "all_32_patches_ms": round(32 * s * 1e3, 3)}
 print("cfg4", res["cfg4_teapot_patch_grid2048"], flush=True)
 t4.domain_status()
+# cfg4, whole job: all 32 patches from one call (bsk_tessellate), positions only and positions + unit normals
+pt = [bspy_amd.DeviceSpline(o, c_, k, cf, np.float32) for (o, c_, k, cf) in cases.teapot_patches(g)]
+pos = torch.empty((32, 3, 2048, 2048), dtype=torch.float32, device="cuda")
+nrm = torch.empty_like(pos)
+s = timed(lambda: bspy_amd.tessellate_tables(pt, (gg, gg), normals=False, out=(pos, None), check=False), steps=10, warm=2)
+res["cfg4_teapot_32_patches_positions"] = {"ms": round(s * 1e3, 4), "Mevals_s": round(32 * npt / s / 1e6, 1), "GBs": round(32 * 12 * npt / s / 1e9, 1)}
+print("cfg4 batch", res["cfg4_teapot_32_patches_positions"], flush=True)
+s = timed(lambda: bspy_amd.tessellate_tables(pt, (gg, gg), out=(pos, nrm), check=False), steps=10, warm=2)
+res["cfg4_teapot_32_patches_positions_normals"] = {"ms": round(s * 1e3, 4), "Mevals_s": round(32 * npt / s / 1e6, 1), "GBs": round(32 * 24 * npt / s / 1e9, 1)}
+print("cfg4 batch + normals", res["cfg4_teapot_32_patches_positions_normals"], flush=True)
+pt[0].domain_status()
+del pos, nrm
 # cfg5: trivariate order 5, 40^3, nDep 4, fp32, 50 M points total over 8 GPUs -> 6.25 M per GPU; time 10 M here
 nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
 n5 = 10_000_000
