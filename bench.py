@@ -74,6 +74,58 @@ def pmc_traffic(op, n):
         return None
 
 
+def other_configs(torch, tables, u, v, n):
+    """The other BASELINE configs on this GPU, timed after the headline (diagnostic; device-resident
+    I/O, steady state): cfg3 derivative / fused jacobian on the same batch, cfg4 = the 32 teapot
+    patches on a 2048 x 2048 grid from one bsk_tessellate call, cfg5 = trivariate order 5, 40^3 x 4
+    fp32 on 10 M points (cell-order pipeline)."""
+    import cases
+    import bspy_amd
+
+    def timed(f, steps, spin_s=0.06):
+        t_end = time.perf_counter() + spin_s      # clock spin-up (the CPU legs before this leave the GPU idle)
+        while time.perf_counter() < t_end:
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps * 1e-3
+
+    def row(sec, evals, bytes_per_eval):
+        return {"ms": round(sec * 1e3, 4), "Mevals_s": round(evals / sec / 1e6, 1),
+                "hbm_frac": round(bytes_per_eval * evals / sec / 1e9 / HBM_PEAK_GBS, 4)}
+
+    res = {}
+    try:
+        out = torch.empty((3, n), dtype=torch.float64, device=u.device)
+        jout = torch.empty((3, 2, n), dtype=torch.float64, device=u.device)
+        res["cfg3_derivative_1_1"] = row(timed(lambda: tables.evaluate_device([u, v], [1, 1], out=out, check=False), 30), n, 40)
+        res["cfg3_jacobian_fused"] = row(timed(lambda: tables.jacobian_device([u, v], out=jout, check=False), 30), n, 64)
+        tables.domain_status()
+        del out, jout
+        g = np.load(os.path.join(ROOT, "tests", "golden", "reference_tables.npz"))
+        patches = [bspy_amd.DeviceSpline(o, c, k, cf, np.float32) for (o, c, k, cf) in cases.teapot_patches(g)]
+        gg = torch.linspace(0, 1, 2048, dtype=torch.float32, device=u.device)
+        pos = torch.empty((32, 3, 2048, 2048), dtype=torch.float32, device=u.device)
+        sec = timed(lambda: bspy_amd.tessellate_tables(patches, (gg, gg), normals=False, out=(pos, None), check=False), 10)
+        res["cfg4_teapot_32_patches_grid2048"] = row(sec, 32 * 2048 * 2048, 12)
+        patches[0].domain_status()
+        del pos
+        nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
+        t5 = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt)
+        p5 = [torch.rand(n, dtype=torch.float32, device=u.device) for _ in range(3)]
+        o5 = torch.empty((4, n), dtype=torch.float32, device=u.device)
+        res["cfg5_trivariate_f32"] = row(timed(lambda: t5.evaluate_device(p5, out=o5, check=False), 10), n, 28)
+        t5.domain_status()
+    except Exception as e:  # diagnostic only: never fail the headline line
+        res["error"] = repr(e)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +134,7 @@ def main():
     ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian", "normal"], default="evaluate")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (reported beside the headline, N=1 only)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--spinup", type=int, default=300, help="untimed launches before warm-up (clock ramp)")
     args = ap.parse_args()
@@ -219,6 +272,8 @@ def main():
         }
         if gathered is not None:
             res["with_allgather"] = gathered
+        if world == 1 and not args.no_extra and args.op == "evaluate":
+            res["other_configs"] = other_configs(torch, tables, u, v, n)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(order, ncoef, knots, coefs, args.cpu_sample)
         print(json.dumps(res), flush=True)
