@@ -18,7 +18,6 @@ calls are batches of one.  ``evaluate_batch`` / ``jacobian_batch`` are the batch
 entry points behind ``Spline.evaluate`` / ``Spline.derivative`` (reference:
 ``np.frompyfunc`` loop, bspy/spline.py:757-770, :936-949).
 """
-import zlib
 
 import numpy as np
 
@@ -36,11 +35,28 @@ def compute_dtype(self):
     return np.dtype(np.float64)
 
 
+_MIX_WEIGHTS = {}
+
+
+def _mix(arr):
+    """Position-sensitive 64-bit hash of an array's bytes: sum of the 8-byte words times fixed odd
+    multipliers, mod 2^64 (vectorised: ~5 us for the 96 KB of a 64 x 64 x 3 table where adler32
+    takes ~40 us - this runs on every call, single-point calls included)."""
+    b = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
+    n8 = b.size // 8
+    w = b[:n8 * 8].view(np.uint64)
+    m = _MIX_WEIGHTS.get(n8)
+    if m is None:
+        m = np.random.default_rng(0x5EED + n8).integers(0, 2 ** 63, n8, dtype=np.uint64)
+        m = m * np.uint64(2) + np.uint64(1)
+        _MIX_WEIGHTS[n8] = m
+    h = int(np.dot(w, m))                       # integer dot product: wraps mod 2^64, no temporary
+    return (h, bytes(b[n8 * 8:])) if b.size != n8 * 8 else h
+
+
 def _fingerprint(self):
-    h = zlib.adler32(np.ascontiguousarray(self.coefs).view(np.uint8).reshape(-1))
-    for k in self.knots:
-        h = zlib.adler32(np.ascontiguousarray(k).view(np.uint8).reshape(-1), h)
-    return (h, self.coefs.shape, str(self.coefs.dtype), tuple(len(k) for k in self.knots))
+    return (_mix(self.coefs), tuple(_mix(k) for k in self.knots), self.coefs.shape, str(self.coefs.dtype),
+            tuple(len(k) for k in self.knots))
 
 
 def device_tables(self, device=None):
@@ -55,7 +71,7 @@ def device_tables(self, device=None):
     entry = cache.get(device)
     if entry is not None and entry[1] == fp:
         return entry[0]
-    if entry is not None and entry[1][1:] == fp[1:] and entry[0].dtype == dt:
+    if entry is not None and entry[1][2:] == fp[2:] and entry[0].dtype == dt:
         entry[0].update(self.knots, self.coefs)
         cache[device] = (entry[0], fp)
         return entry[0]
@@ -94,10 +110,9 @@ def _point(self, with_respect_to, uvw):
         raise ValueError(f"Incorrect number of derivative orders: {len(with_respect_to)}")
     tables = device_tables(self)
     try:
-        out = tables.evaluate([uvw[i:i + 1] for i in range(self.nInd)], with_respect_to)
+        return tables.point(uvw, with_respect_to).astype(self.coefs.dtype, copy=False)   # reference: coefs' dtype
     except nv.DomainError:
         raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
-    return out[:, 0]
 
 
 def evaluate(self, uvw):
@@ -118,10 +133,10 @@ def jacobian(self, uvw):
         raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
     tables = device_tables(self)
     try:
-        out = tables.jacobian([uvw[i:i + 1] for i in range(self.nInd)])
+        out = tables.point(uvw, jacobian=True)
     except nv.DomainError:
         raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
-    return out[:, :, 0].astype(self.coefs.dtype, copy=False)
+    return out.astype(self.coefs.dtype, copy=False)
 
 
 def normal(self, uvw, normalize=True, indices=None):

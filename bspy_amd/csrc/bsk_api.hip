@@ -81,6 +81,8 @@ struct bsk_spline_s {
     DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
     DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
     std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
+    void *pin = nullptr;                // pinned, device-mapped host buffer of the small-call path (run_small)
+    size_t pin_cap = 0;
 };
 
 template <typename T>
@@ -348,6 +350,8 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->out_ws.release();
     s->aux_ws.release();
     s->bin_ws.release();
+    if (s->pin) (void)hipHostFree(s->pin);
+    s->pin = nullptr;
     delete s;
     return BSK_OK;
 }
@@ -861,6 +865,68 @@ extern "C" bsk_status bsk_domain_status(bsk_spline s, void *stream, int64_t *fir
 // ------------------------------------------------------------------------------------
 // evaluate / derivative / jacobian
 // ------------------------------------------------------------------------------------
+// Small BSK_HOST calls (the reference's single-point API lands here): no staging copies.  The
+// parameters are written into a pinned, device-mapped host buffer that the kernels read directly
+// over PCIe; results and the out-of-domain record come back through the same buffer; one
+// synchronisation.  (Five small hipMemcpyAsync calls plus the record query cost ~70 us per call;
+// this path ~20 us.)
+static constexpr long long SMALL_CALL_POINTS = 2048;
+
+__global__ void publish_bad(unsigned long long *bad, unsigned long long *slot)
+{
+    const unsigned long long v = *bad;
+    *slot = v;
+    if (v != NO_BAD) *bad = NO_BAD;
+}
+
+static bsk_status reserve_pin(bsk_spline s, size_t bytes)
+{
+    if (bytes <= s->pin_cap) return BSK_OK;
+    if (s->pin) (void)hipHostFree(s->pin);
+    s->pin = nullptr;
+    s->pin_cap = 0;
+    HIPCHK(hipHostMalloc(&s->pin, bytes, hipHostMallocMapped));
+    s->pin_cap = bytes;
+    return BSK_OK;
+}
+
+// layout of the pinned buffer: [first_bad u64][pad to 64][inputs: rows_in x n][outputs: rows_out x n]
+template <typename T, typename Launch>
+static bsk_status run_small(bsk_spline s, const void *const *uvw, long long n, int rows_out, void *out, hipStream_t st,
+                            int64_t *first_bad, Launch launch)
+{
+    const size_t in_b = sizeof(T) * (size_t)n * s->nInd, out_b = sizeof(T) * (size_t)n * rows_out;
+    bsk_status r = reserve_pin(s, 64 + ((in_b + 63) & ~(size_t)63) + out_b + 64);
+    if (r != BSK_OK) return r;
+    char *hp = static_cast<char *>(s->pin);
+    void *dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, s->pin, 0));
+    char *dbase = static_cast<char *>(dp);
+    unsigned long long *hslot = reinterpret_cast<unsigned long long *>(hp);
+    T *hin = reinterpret_cast<T *>(hp + 64), *din = reinterpret_cast<T *>(dbase + 64);
+    const size_t ooff = 64 + ((in_b + 63) & ~(size_t)63);
+    T *hout = reinterpret_cast<T *>(hp + ooff), *dout = reinterpret_cast<T *>(dbase + ooff);
+    Params<T> prm;
+    for (int iv = 0; iv < MAXI; ++iv) prm.p[iv] = nullptr;
+    for (int iv = 0; iv < s->nInd; ++iv) {
+        memcpy(hin + (size_t)iv * n, uvw[iv], sizeof(T) * (size_t)n);
+        prm.p[iv] = din + (size_t)iv * n;
+    }
+    r = launch(prm, dout);
+    if (r != BSK_OK) return r;
+    hipLaunchKernelGGL(publish_bad, dim3(1), dim3(1), 0, st, s->bad, reinterpret_cast<unsigned long long *>(dbase));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    const unsigned long long v = *hslot;
+    if (v != NO_BAD) {
+        if (first_bad) *first_bad = (int64_t)v;
+        return fail(BSK_ERR_DOMAIN, "parameter outside the spline's domain at flat index " + std::to_string(v));
+    }
+    memcpy(out, hout, out_b);
+    if (first_bad) *first_bad = -1;
+    return BSK_OK;
+}
+
 // BSK_HOST batches are processed in chunks so the staging buffers stay bounded.
 static constexpr long long HOST_CHUNK = 1ll << 24;
 
@@ -882,6 +948,11 @@ static bsk_status run_points(bsk_spline s, bool jac, const int *wrt, const void 
         return jac ? dispatch_jac<T>(s, prm, n, static_cast<T *>(out), st)
                    : dispatch_eval<T>(s, prm, n, static_cast<T *>(out), n, w, st);
     }
+
+    if (n <= SMALL_CALL_POINTS)
+        return run_small<T>(s, uvw, n, outs, out, st, first_bad, [&](const Params<T> &prm, T *dout) {
+            return jac ? dispatch_jac<T>(s, prm, n, dout, st) : dispatch_eval<T>(s, prm, n, dout, n, w, st);
+        });
 
     // host buffers: stage chunk by chunk
     const long long chunk = std::min(n, HOST_CHUNK);
@@ -961,6 +1032,20 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
     const long long chunk = mem == BSK_HOST ? std::min(n, HOST_CHUNK) : n;
     // jacobian workspace (device) for one chunk, unless the normal is fused into the jacobian kernel
     const bool fused = s->nDep == 3 && rowrot_applies<T>(s);
+    if (mem == BSK_HOST && n <= SMALL_CALL_POINTS) {
+        if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)n * s->nDep * s->nInd));
+        return run_small<T>(s, uvw, n, big, out, st, first_bad, [&](const Params<T> &prm, T *dout) -> bsk_status {
+            if (fused) return launch_jac_rowrot<T, true>(s, prm, n, dout, normalize, negate, st);
+            T *dj = static_cast<T *>(s->aux_ws.p);
+            const bsk_status r = dispatch_jac<T>(s, prm, n, dj, st);
+            if (r != BSK_OK) return r;
+            const int grid = (int)std::max<long long>(1, (n + 255) / 256);
+            hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(256), 0, st, dj, s->nInd, s->nDep, n, normalize,
+                               negate, dout);
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        });
+    }
     if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
     T *djac = static_cast<T *>(s->aux_ws.p);
     T *din = nullptr, *dout = static_cast<T *>(out);

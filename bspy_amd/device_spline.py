@@ -104,6 +104,27 @@ class DeviceSpline:
             raise ValueError("parameter arrays must have the same size")
         return ps, n
 
+    def point(self, uvw, wrt=None, jacobian=False):
+        """One parameter point (the reference's single-point API): ``uvw`` = nInd scalars ->
+        ndarray (nDep,) or, with ``jacobian``, (nDep, nInd).  Same C-ABI calls as ``evaluate`` /
+        ``jacobian`` with N = 1 (the library serves such calls through a pinned, device-mapped
+        buffer); only the Python-side argument handling is leaner."""
+        a = np.array(uvw, dtype=self.dtype).reshape(-1)
+        if a.size != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {a.size}")
+        base, isz = a.ctypes.data, a.itemsize
+        ptrs = (ctypes.c_void_p * max(self.nInd, 1))(*[base + i * isz for i in range(self.nInd)])
+        bad = ctypes.c_int64(-1)
+        if jacobian:
+            out = np.empty((self.nDep, self.nInd), self.dtype)
+            st = nv.lib().bsk_jacobian(self._handle, ptrs, 1, nv.BSK_HOST, out.ctypes.data, None, ctypes.byref(bad))
+        else:
+            out = np.empty(self.nDep, self.dtype)
+            st = nv.lib().bsk_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None, ptrs, 1, nv.BSK_HOST,
+                                       out.ctypes.data, None, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out
+
     def evaluate(self, points, wrt=None):
         """points: nInd arrays of N values -> ndarray (nDep, N).  Raises DomainError."""
         ps, n = self._host_params(points)
