@@ -865,12 +865,18 @@ extern "C" bsk_status bsk_domain_status(bsk_spline s, void *stream, int64_t *fir
 // ------------------------------------------------------------------------------------
 // evaluate / derivative / jacobian
 // ------------------------------------------------------------------------------------
-// Small BSK_HOST calls (the reference's single-point API lands here): no staging copies.  The
+// Small BSK_HOST calls (the reference's single-point API lands here; up to 65536 points, the measured
+// crossover with the staged path - BSK_SMALL_POINTS overrides): no staging copies.  The
 // parameters are written into a pinned, device-mapped host buffer that the kernels read directly
 // over PCIe; results and the out-of-domain record come back through the same buffer; one
 // synchronisation.  (Five small hipMemcpyAsync calls plus the record query cost ~70 us per call;
 // this path ~20 us.)
-static constexpr long long SMALL_CALL_POINTS = 2048;
+static long long small_call_points()
+{
+    static const long long v = getenv("BSK_SMALL_POINTS") ? atoll(getenv("BSK_SMALL_POINTS")) : 65536;
+    return v;
+}
+#define SMALL_CALL_POINTS small_call_points()
 
 __global__ void publish_bad(unsigned long long *bad, unsigned long long *slot)
 {

@@ -8,12 +8,13 @@ nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(2)
 s = Spline(nind, ndep, order, ncoef, knots, coefs)
 t = s.device_tables()
 rng = np.random.default_rng(0)
-for n in (1, 16, 256, 4096):
+for n in (1, 16, 256, 2048, 4096, 16384, 65536, 262144):
     u, v = rng.random(n), rng.random(n)
     for _ in range(50): t.evaluate([u, v])
     t0 = time.perf_counter()
-    for _ in range(500): t.evaluate([u, v])
-    dt_dev = (time.perf_counter() - t0) / 500
+    reps = 500 if n <= 4096 else 50
+    for _ in range(reps): t.evaluate([u, v])
+    dt_dev = (time.perf_counter() - t0) / reps
     print(f"DeviceSpline.evaluate host arrays n={n:5d}: {dt_dev * 1e6:8.1f} us per call")
 for name, f in (("Spline.evaluate([u, v]) single point", lambda: s.evaluate([0.3, 0.7])),
                 ("Spline.jacobian([u, v]) single point", lambda: s.jacobian([0.3, 0.7])),
