@@ -751,7 +751,8 @@ static bsk_status launch_jac_stream(bsk_spline s, size_t lds, const Params<T> &p
 
 // The asm-LDS kernels (tile / stream) cover orders 1..5: at order 6 their register windows
 // (36-value slabs, 20 table values per variable) no longer fit without spilling, which those
-// kernels must never do (check_spills.py); order 6 runs on eval_fixed.
+// kernels must never do (check_spills.py); order 6 runs on eval_fixed - except curves, whose single
+// window row fits up to order 8 (dispatched before this switch).
 #define BSK_ORDER_SWITCH5(NIND, CALL)                       \
     switch (s->order[0]) {                                  \
         case 1: return CALL(NIND, 1);                       \
@@ -767,6 +768,15 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
                                 const Wrt &w, hipStream_t st)
 {
     if (n <= 0) return BSK_OK;
+    if (s->nInd == 1 && s->order[0] >= 6 && s->order[0] <= 8 && s->variant != 1) {
+        // curves of order 6..8: one window row per dependent variable still fits the registers
+        const size_t lds = tile_lds_bytes<T>(s, false);
+        if (lds != 0) switch (s->order[0]) {
+            case 6: return launch_eval_lds<T, 1, 6>(s, lds, prm, n, out, ostride, w, st);
+            case 7: return launch_eval_lds<T, 1, 7>(s, lds, prm, n, out, ostride, w, st);
+            default: return launch_eval_lds<T, 1, 8>(s, lds, prm, n, out, ostride, w, st);
+        }
+    }
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         // table image fits in LDS: eval_rowrot (surfaces of order 2 / 4) or eval_stream
         const size_t lds = tile_lds_bytes<T>(s, false);
@@ -801,6 +811,14 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
 {
     if (n <= 0) return BSK_OK;
     if (rowrot_applies<T>(s)) return launch_jac_rowrot<T, false>(s, prm, n, out, 0, 0, st);
+    if (s->nInd == 1 && s->order[0] >= 6 && s->order[0] <= 8 && s->variant != 1) {
+        const size_t lds = tile_lds_bytes<T>(s, false);
+        if (lds != 0) switch (s->order[0]) {
+            case 6: return launch_jac_stream<T, 1, 6>(s, lds, prm, n, out, st);
+            case 7: return launch_jac_stream<T, 1, 7>(s, lds, prm, n, out, st);
+            default: return launch_jac_stream<T, 1, 8>(s, lds, prm, n, out, st);
+        }
+    }
     if (has_fixed_path(s) && s->variant != 1 && s->order[0] <= 5) {
         const size_t lds = tile_lds_bytes<T>(s, false);
         if (lds != 0) {

@@ -26,13 +26,17 @@ __device__ __forceinline__ void lds_wait_c(T (&v)[CAP])
 template <typename T, int C>
 __device__ __forceinline__ void lds_tie_row(T (&v)[C])
 {
-    static_assert(C >= 1 && C <= 6, "row length");
+    static_assert(C >= 1 && C <= 8, "row length");
     if constexpr (C == 1) asm volatile("" : "+v"(v[0]) :: "memory");
     else if constexpr (C == 2) asm volatile("" : "+v"(v[0]), "+v"(v[1]) :: "memory");
     else if constexpr (C == 3) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) :: "memory");
     else if constexpr (C == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
     else if constexpr (C == 5) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) :: "memory");
-    else asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) :: "memory");
+    else if constexpr (C == 6) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) :: "memory");
+    else if constexpr (C == 7)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) :: "memory");
+    else
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 }
 
 template <typename T, int R, int C, int A = 0>

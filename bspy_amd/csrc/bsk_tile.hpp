@@ -52,7 +52,7 @@ struct LdsRead<float> {
 template <int CNT, int N, typename T, int CAP>
 __device__ __forceinline__ void lds_wait_n(T (&v)[CAP])
 {
-    static_assert(N >= 1 && N <= 6 && N <= CAP, "row length");
+    static_assert(N >= 1 && N <= 8 && N <= CAP, "row length");
     static_assert(CNT >= 0 && CNT <= 15, "lgkmcnt is 4 bits");
     if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v[0]) : "n"(CNT) : "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(CNT) : "memory");
@@ -63,9 +63,17 @@ __device__ __forceinline__ void lds_wait_n(T (&v)[CAP])
     else if constexpr (N == 5)
         asm volatile("s_waitcnt lgkmcnt(%5)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) : "n"(CNT) : "memory");
-    else
+    else if constexpr (N == 6)
         asm volatile("s_waitcnt lgkmcnt(%6)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "n"(CNT) : "memory");
+    else if constexpr (N == 7)
+        asm volatile("s_waitcnt lgkmcnt(%7)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6])
+                     : "n"(CNT) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                     : "n"(CNT) : "memory");
 }
 
 template <int CNT, typename T, int N>
