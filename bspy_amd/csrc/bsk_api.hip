@@ -474,6 +474,18 @@ static size_t tile_lds_bytes(bsk_spline s, bool /*unused*/)
 static bool has_fixed_path(bsk_spline s);
 
 // eval_rowrot / jac_rowrot / fused normal: surfaces of order 2 or 4 whose odd-stride image fits LDS
+// Points per launch of the rowrot kernels (32-bit indices).  BSK_RR_CHUNK lowers it so that the
+// chunk loop can be exercised by tests without a 2^28-point batch.
+static long long rr_chunk_points()
+{
+    static const long long v = [] {
+        const char *e = getenv("BSK_RR_CHUNK");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 && x < (long long)RR_MAX_CHUNK ? x : (long long)RR_MAX_CHUNK;
+    }();
+    return v;
+}
+
 template <typename T>
 static size_t rowrot_lds_bytes(bsk_spline s)
 {
@@ -511,8 +523,9 @@ static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long lon
     // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
     const int nd = (NORMAL || s->nDep > 3) ? 0 : s->nDep;
     // 32-bit point indices inside a launch: chunks of at most RR_MAX_CHUNK points
-    for (long long n0 = 0; n0 < n; n0 += RR_MAX_CHUNK) {
-        const long long m = std::min<long long>(n - n0, RR_MAX_CHUNK);
+    const long long cmax = rr_chunk_points();
+    for (long long n0 = 0; n0 < n; n0 += cmax) {
+        const long long m = std::min<long long>(n - n0, cmax);
         const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu));
         Params<T> cp = prm;
         for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
@@ -560,8 +573,9 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
     default: BSK_ROWROT(DERIV_, 0); break;                                                                               \
     }
             // 32-bit point indices inside a launch: chunks of at most RR_MAX_CHUNK points
-            for (long long n0 = 0; n0 < n; n0 += RR_MAX_CHUNK) {
-                const long long m = std::min<long long>(n - n0, RR_MAX_CHUNK);
+            const long long cmax = rr_chunk_points();
+            for (long long n0 = 0; n0 < n; n0 += cmax) {
+                const long long m = std::min<long long>(n - n0, cmax);
                 const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu));
                 Params<T> cp = prm;
                 for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;

@@ -14,6 +14,8 @@ import pytest
 
 import cases
 import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import bspy_amd
 from bspy_amd import DeviceSpline, Spline
 
@@ -362,6 +364,38 @@ def test_pair_kernels_odd_sizes_views_and_domain_index():
         with pytest.raises(bspy_amd.DomainError) as e:
             t.jacobian([ub[:-1], v[:-1]] if badi < u.size - 1 else [ub, v])
         assert e.value.index == badi
+
+
+def test_rowrot_launch_chunks():
+    """The rowrot kernels index points with 32 bits and the launcher cuts batches at 2^28 points;
+    BSK_RR_CHUNK lowers the cut so the chunk loop (pointer offsets, row strides, first-offender
+    index across chunks) runs on a small batch.  Separate process: the limit is read once."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import cases, bspy_amd
+        c = {x.name: x for x in cases.parity_cases()}["cfg2_bicubic"]
+        t = bspy_amd.DeviceSpline(c.order, c.nCoef, c.knots, c.coefs)
+        rng = np.random.default_rng(5)
+        n = 10_007
+        u, v = rng.random(n), rng.random(n)
+        np.save(sys.argv[1], np.concatenate([t.evaluate([u, v]).ravel(), t.evaluate([u, v], [1, 1]).ravel(),
+                                             t.jacobian([u, v]).ravel(), t.normal([u, v]).ravel()]))
+        ub = u.copy(); ub[7_777] = 4.0
+        try:
+            t.evaluate([ub, v]); print("no error")
+        except bspy_amd.DomainError as e:
+            print("bad", e.index)
+    """) % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for env_extra in ({}, {"BSK_RR_CHUNK": "4096"}):
+        f = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rr_chunk_{len(outs)}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env_extra), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "bad 7777" in r.stdout
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("variant", ["1", "4", "9"])
