@@ -966,7 +966,17 @@ static bsk_status run_small(bsk_spline s, const void *const *uvw, long long n, i
 }
 
 // BSK_HOST batches are processed in chunks so the staging buffers stay bounded.
-static constexpr long long HOST_CHUNK = 1ll << 24;
+static long long host_chunk_points()
+{
+    // BSK_HOST_CHUNK lowers the chunk so that tests can run the chunk loops on small batches
+    static const long long v = [] {
+        const char *e = getenv("BSK_HOST_CHUNK");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 ? x : 1ll << 24;
+    }();
+    return v;
+}
+#define HOST_CHUNK host_chunk_points()
 
 template <typename T>
 static bsk_status run_points(bsk_spline s, bool jac, const int *wrt, const void *const *uvw, long long n, bsk_mem mem,

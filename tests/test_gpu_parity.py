@@ -366,7 +366,7 @@ def test_pair_kernels_odd_sizes_views_and_domain_index():
         assert e.value.index == badi
 
 
-def test_rowrot_launch_chunks():
+def test_launch_and_host_chunk_loops():
     """The rowrot kernels index points with 32 bits and the launcher cuts batches at 2^28 points;
     BSK_RR_CHUNK lowers the cut so the chunk loop (pointer offsets, row strides, first-offender
     index across chunks) runs on a small batch.  Separate process: the limit is read once."""
@@ -387,15 +387,30 @@ def test_rowrot_launch_chunks():
             t.evaluate([ub, v]); print("no error")
         except bspy_amd.DomainError as e:
             print("bad", e.index)
+        # staged host path (more points than the zero-copy path takes): chunk loop of BSK_HOST_CHUNK
+        m = 150_001
+        U, V = rng.random(m), rng.random(m)
+        c4 = {x.name: x for x in cases.parity_cases()}["surface_o3x4"]
+        t4 = bspy_amd.DeviceSpline(c4.order, c4.nCoef, c4.knots, c4.coefs)
+        dom = [(k[o - 1], k[nc]) for k, o, nc in zip(c4.knots, c4.order, c4.nCoef)]
+        P = [lo + (hi - lo) * rng.random(m) for lo, hi in dom]
+        np.save(sys.argv[1] + ".host.npy", np.concatenate([t.evaluate([U, V]).ravel(), t.jacobian([U, V]).ravel(), t.normal([U, V]).ravel(),
+                                                            t.curvature([U[:70_000], V[:70_000]]).ravel(), t4.evaluate(P, [1, 0]).ravel()]))
+        Ub = U.copy(); Ub[123_456] = -1.0
+        try:
+            t.jacobian([Ub, V]); print("no error")
+        except bspy_amd.DomainError as e:
+            print("hostbad", e.index)
     """) % (ROOT, os.path.join(ROOT, "tests"))
     outs = []
-    for env_extra in ({}, {"BSK_RR_CHUNK": "4096"}):
+    for env_extra in ({}, {"BSK_RR_CHUNK": "4096", "BSK_HOST_CHUNK": "40000", "BSK_SMALL_POINTS": "1000"}):
         f = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rr_chunk_{len(outs)}.npy")
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env_extra), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert "bad 7777" in r.stdout
-        outs.append(np.load(f))
-    assert np.array_equal(outs[0], outs[1])
+        assert "bad 7777" in r.stdout and "hostbad 123456" in r.stdout, r.stdout
+        outs.append((np.load(f), np.load(f + ".host.npy")))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
 
 
 @pytest.mark.parametrize("variant", ["1", "4", "9"])
