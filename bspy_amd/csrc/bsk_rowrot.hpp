@@ -328,6 +328,9 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 
         const unsigned off = n * (unsigned)sizeof(T);
         T *o = out;
+        // the window phase is the LDS-bound part: its waves issue ahead of the ones still in the
+        // (VALU-bound) recursion (measured 1 %)
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int dep = 0; dep < nDep; ++dep) {
             T c[O][O];
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(TILE) void eval_rowrot(const Desc<T> d, const TileD
 #pragma unroll
             for (int a = 0; a < O; ++a) ra[a] += dstride;
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
         T *o = out;
         T su[3], sv[3];                    // NORMAL: the two tangent vectors
         const int ndep = NORMAL ? 3 : (ND > 0 ? ND : d.nDep);
+        __builtin_amdgcn_s_setprio(3);     // see eval_rowrot
 #pragma unroll
         for (int dep = 0; dep < ndep; ++dep) {
             T c[O][O];
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
 #pragma unroll
             for (int a = 0; a < O; ++a) ra[a] += dstride;
         }
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (NORMAL) {
             // cofactors of the 3 x 2 tangent space: normal[i] = (-1)^i det(rows != i)
             T nx = su[1] * sv[2] - sv[1] * su[2];
