@@ -307,6 +307,12 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream(const Desc<T> d, con
         find_spans<T, NIND>(tab_a, lut_a, d, td, steps, u, ix);
         T b[NIND][O];
         bases_all<T, NIND, O, DERIV>(tab_a, d, ix, u, wrt, b);
+        // Take the prefetched parameters HERE, before this iteration's stores are issued: the wait
+        // hipcc inserts then covers the loads only (issued half an iteration ago).  At the end of
+        // the iteration it would be vmcnt(0) behind a run-time number of stores, i.e. every
+        // iteration would wait for its own stores to be acknowledged.
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(un[iv]));
         unsigned caddr = coef_a;
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)((ix[iv] - O) * d.cstride[iv + 1]) * (unsigned)sizeof(T);
@@ -475,6 +481,8 @@ __global__ __launch_bounds__(STREAM_BLOCK) void jac_stream(const Desc<T> d, cons
             }
             bases_d1_compute<T, NIND, O, 0>(u, kn, rc, b, db);
         }
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(un[iv]));   // see eval_stream: before the stores
         unsigned caddr = coef_a;
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)((ix[iv] - O) * d.cstride[iv + 1]) * (unsigned)sizeof(T);
