@@ -313,7 +313,9 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
     HIPCHK_C(hipMalloc(&s->coef, std::max<size_t>(16, s->esize * (size_t)coef_len)));
     {
         const size_t tbytes = s->esize * (size_t)tab_len + s->esize * (size_t)coef_len;
-        bool fixed = s->same_order && nInd <= 3 && order[0] <= 6;
+        int omax = 0;
+        for (int iv = 0; iv < nInd; ++iv) omax = std::max(omax, order[iv]);
+        bool fixed = nInd <= 3 && omax <= 6;                  // gather / cell-order kernels: any mix of orders <= 6
         if (fixed && nDep <= 4 && tbytes + 8192 > s->lds_max)
             HIPCHK_C(hipMalloc(&s->coef_aos, std::max<size_t>(16, s->esize * (size_t)coef_len)));
     }
@@ -419,6 +421,27 @@ static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T>
     } else {
         HIPCHK(allow_lds(eval_fixed<T, NIND, O, false>, p.lds_bytes));
         hipLaunchKernelGGL((eval_fixed<T, NIND, O, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, ostride, w, s->bad);
+    }
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
+// Variables of different orders, all <= 6, nInd <= 3: eval_mixed at OMAX = the largest order.
+template <typename T, int NIND, int OMAX>
+static bsk_status launch_eval_mixed(bsk_spline s, const Plan &p, const Params<T> &prm, long long n, T *out,
+                                    long long ostride, const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *coef = static_cast<const T *>(s->coef);
+    if (p.lds_coefs) {
+        HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, true>, p.lds_bytes));
+        hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
+                           prm, n, out, ostride, w, s->bad);
+    } else {
+        HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, false>, p.lds_bytes));
+        hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
     }
     HIPCHK(hipGetLastError());
@@ -616,9 +639,15 @@ static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long lo
     const T *aos = static_cast<const T *>(s->coef_aos);
 #define GATHER_ND(ND)                                                                                             \
     case ND:                                                                                                      \
-        HIPCHK(allow_lds(eval_gather<T, NIND, O, ND>, lds));                                                      \
-        hipLaunchKernelGGL((eval_gather<T, NIND, O, ND>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, n, out, \
-                           ostride, w, s->bad);                                                                   \
+        if (s->same_order) {                                                                                      \
+            HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, false>, lds));                                           \
+            hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, false>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, \
+                               n, out, ostride, w, s->bad);                                                       \
+        } else {                                                                                                  \
+            HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, true>, lds));                                            \
+            hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, true>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, \
+                               n, out, ostride, w, s->bad);                                                       \
+        }                                                                                                         \
         break;
     switch (s->nDep) {
         GATHER_ND(1) GATHER_ND(2) GATHER_ND(3) GATHER_ND(4)
@@ -651,7 +680,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         }
         const Desc<T> &d = desc_of<T>(s);
         BinPlan bp;
-        const int s0 = s->ncoef[0] - O + 1, s1 = s->ncoef[1] - O + 1;
+        const int s0 = s->ncoef[0] - s->order[0] + 1, s1 = s->ncoef[1] - s->order[1] + 1;   // spans (O = largest order)
         bp.sh0 = bp.sh1 = 0;
         auto cells_of = [&](int sh0, int sh1) { return (((s0 - 1) >> sh0) + 1) * (((s1 - 1) >> sh1) + 1); };
         while (cells_of(bp.sh0, bp.sh1) > BIN_MAX_CELLS) {
@@ -679,7 +708,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const T *aos = static_cast<const T *>(s->coef_aos);
         const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
         // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
-        const size_t rows_b = (size_t)((1 << bp.sh0) + O - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + O - 1) : 1);
+        const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
         const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
         const bool bundle_ok = s->variant != 6 && tab_b + bundle_b <= s->lds_max / 2;
 #define BINNED_ND(ND)                                                                                                    \
@@ -701,14 +730,22 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(BIN_BLOCK), sizeof(unsigned) * (size_t)bp.cells, \
                            st, bp, prm, n, cell, M, start, rec, slot);                                                   \
-        if (bundle_ok) {                                                                                                 \
-            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND>, tab_b + bundle_b));                                        \
-            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d, bp,   \
-                               tab, aos, start, rec, n, tmp, w);                                                         \
+        if (bundle_ok && s->same_order) {                                                                                \
+            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, false>, tab_b + bundle_b));                                 \
+            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, false>), dim3(egrid), dim3(256), tab_b + bundle_b, st,   \
+                               d, bp, tab, aos, start, rec, n, tmp, w);                                                  \
+        } else if (bundle_ok) {                                                                                          \
+            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, true>, tab_b + bundle_b));                                  \
+            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, true>), dim3(egrid), dim3(256), tab_b + bundle_b, st,    \
+                               d, bp, tab, aos, start, rec, n, tmp, w);                                                  \
+        } else if (s->same_order) {                                                                                      \
+            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND, false>, tab_b));                                                \
+            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND, false>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos,     \
+                               rec, n, tmp, w);                                                                          \
         } else {                                                                                                         \
-            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND>, tab_b));                                                       \
-            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos, rec, n,    \
-                               tmp, w);                                                                                  \
+            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND, true>, tab_b));                                                 \
+            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND, true>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos,      \
+                               rec, n, tmp, w);                                                                          \
         }                                                                                                                \
         hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(egrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
     } break;
@@ -817,6 +854,38 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         else { BSK_ORDER_SWITCH(3, CALL_EVAL) }
 #undef CALL_EVAL
     }
+    if (!s->same_order && s->nInd >= 1 && s->nInd <= 3 && s->variant != 1) {
+        int omax = 0;
+        for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
+        if (omax >= 2 && omax <= 6 && s->coef_aos) {
+            // table too large for LDS: control-point-major gather / cell-order pipeline at O = omax
+#define CALL_GATHER_M(NIND)                                                                       \
+    switch (omax) {                                                                               \
+        case 2: return gather_or_binned<T, NIND, 2>(s, prm, n, out, ostride, w, st);              \
+        case 3: return gather_or_binned<T, NIND, 3>(s, prm, n, out, ostride, w, st);              \
+        case 4: return gather_or_binned<T, NIND, 4>(s, prm, n, out, ostride, w, st);              \
+        case 5: return gather_or_binned<T, NIND, 5>(s, prm, n, out, ostride, w, st);              \
+        default: return gather_or_binned<T, NIND, 6>(s, prm, n, out, ostride, w, st);             \
+    }
+            if (s->nInd == 2) { CALL_GATHER_M(2) }
+            else if (s->nInd == 3) { CALL_GATHER_M(3) }
+#undef CALL_GATHER_M
+        }
+        if (omax >= 2 && omax <= 6) {
+            const Plan p = make_plan<T>(s, n);
+#define CALL_MIXED(NIND)                                                                          \
+    switch (omax) {                                                                               \
+        case 2: return launch_eval_mixed<T, NIND, 2>(s, p, prm, n, out, ostride, w, st);          \
+        case 3: return launch_eval_mixed<T, NIND, 3>(s, p, prm, n, out, ostride, w, st);          \
+        case 4: return launch_eval_mixed<T, NIND, 4>(s, p, prm, n, out, ostride, w, st);          \
+        case 5: return launch_eval_mixed<T, NIND, 5>(s, p, prm, n, out, ostride, w, st);          \
+        default: return launch_eval_mixed<T, NIND, 6>(s, p, prm, n, out, ostride, w, st);         \
+    }
+            if (s->nInd == 2) { CALL_MIXED(2) }
+            else if (s->nInd == 3) { CALL_MIXED(3) }
+#undef CALL_MIXED
+        }
+    }
     return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
 }
 
@@ -859,11 +928,12 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
         else { BSK_ORDER_SWITCH(3, CALL_JAC) }
 #undef CALL_JAC
     }
-    // generic: nInd unit-derivative passes, as the reference does (_spline_evaluation.py:205-213)
+    // otherwise nInd unit-derivative passes, as the reference does (_spline_evaluation.py:205-213), each on the
+    // best evaluation kernel for the shape (mixed orders: eval_mixed / gather; else eval_generic)
     for (int j = 0; j < s->nInd; ++j) {
         Wrt w;
         for (int iv = 0; iv < MAXI; ++iv) w.w[iv] = (iv == j);
-        bsk_status r = launch_eval_generic<T>(s, prm, n, out + (long long)j * n, (long long)s->nInd * n, w, st);
+        bsk_status r = dispatch_eval<T>(s, prm, n, out + (long long)j * n, (long long)s->nInd * n, w, st);
         if (r != BSK_OK) return r;
     }
     return BSK_OK;

@@ -55,8 +55,8 @@ struct __attribute__((aligned(16))) BinOut {
 template <typename T, int O>
 __device__ __forceinline__ int bin_cell(const T *stab, const Desc<T> &d, const BinPlan &bp, T u0, T u1)
 {
-    const int i0 = find_span<T>(stab + d.off[0], O, d.ncoef[0], d.steps[0], u0) - O;
-    const int i1 = find_span<T>(stab + d.off[1], O, d.ncoef[1], d.steps[1], u1) - O;
+    const int i0 = find_span<T>(stab + d.off[0], d.order[0], d.ncoef[0], d.steps[0], u0) - d.order[0];
+    const int i1 = find_span<T>(stab + d.off[1], d.order[1], d.ncoef[1], d.steps[1], u1) - d.order[1];
     return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
 }
 
@@ -158,8 +158,73 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter(const BinPlan bp, const
     }
 }
 
+// Window contraction on a control-point-major table with strides s0 / s1 (control points) of the
+// first / second variable; the last variable is contiguous.  Same operation order as eval_gather.
+// O is the spline's LARGEST order: a variable of lower order has its basis right aligned
+// (basis_bounded) and its first pad = O - order window entries are neither weighted nor loaded
+// (MIXED; splines of one common order compile the tests out).
+template <typename T, int NIND, int O, int ND, bool MIXED, typename CP>
+__device__ __forceinline__ void window_contract(CP w0, int s0, int s1, const int (&pad)[NIND], const T (&b)[NIND][O],
+                                                T (&r)[ND])
+{
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) r[dd] = T(0);
+    if constexpr (NIND == 2) {
+#pragma unroll
+        for (int a = 0; a < O; ++a) {
+            if (!MIXED || a >= pad[0]) {
+                T t[ND];
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    if (!MIXED || k >= pad[1]) {
+                        T c[ND];
+                        load_cp<T, ND>(w0 + (a * s0 + k) * ND, c);
+#pragma unroll
+                        for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[1][k];
+                    }
+                }
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < O; ++a) {
+            if (!MIXED || a >= pad[0]) {
+                T s[ND];
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) s[dd] = T(0);
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    if (!MIXED || k >= pad[1]) {
+                        T t[ND];
+#pragma unroll
+                        for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
+                        CP row = w0 + (a * s0 + k * s1) * ND;
+#pragma unroll
+                        for (int m = 0; m < O; ++m) {
+                            if (!MIXED || m >= pad[2]) {
+                                T c[ND];
+                                load_cp<T, ND>(row + m * ND, c);
+#pragma unroll
+                                for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[2][m];
+                            }
+                        }
+#pragma unroll
+                        for (int dd = 0; dd < ND; ++dd) s[dd] += t[dd] * b[1][k];
+                    }
+                }
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) r[dd] += s[dd] * b[0][a];
+            }
+        }
+    }
+}
+
 // eval_gather's arithmetic on the records (slot order); results control-point-major in tmp[slot]
-template <typename T, int NIND, int O, int ND>
+template <typename T, int NIND, int O, int ND, bool MIXED>
 __global__ __launch_bounds__(256) void eval_binned(const Desc<T> d, const T *__restrict__ gtab, const T *__restrict__ aos,
                                                    const BinRec<T, NIND> *__restrict__ rec, const long long N,
                                                    BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
@@ -172,6 +237,9 @@ __global__ __launch_bounds__(256) void eval_binned(const Desc<T> d, const T *__r
     cs[NIND - 1] = 1;
 #pragma unroll
     for (int iv = NIND - 2; iv >= 0; --iv) cs[iv] = cs[iv + 1] * d.ncoef[iv + 1];
+    int pad[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) pad[iv] = O - d.order[iv];
 
     // consecutive slots to consecutive lanes, a workgroup walks a contiguous range (neighbouring
     // waves share cells -> the row bundle stays in this CU's L1)
@@ -185,111 +253,18 @@ __global__ __launch_bounds__(256) void eval_binned(const Desc<T> d, const T *__r
         for (int iv = 0; iv < NIND; ++iv) {
             const T u = rc.v[iv];
             const T *tab = stab + d.off[iv];
-            const int ix = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u);
-            basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
+            const int ix = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
+            if constexpr (MIXED) basis_bounded<T, O>(tab, d.nk[iv], d.order[iv], ix, u, wrt.w[iv], b[iv]);
+            else basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
             base += (ix - O) * cs[iv];
         }
         const T *__restrict__ w0 = aos + (long long)base * ND;
         T r[ND];
-#pragma unroll
-        for (int dd = 0; dd < ND; ++dd) r[dd] = T(0);
-        if constexpr (NIND == 2) {
-#pragma unroll
-            for (int a = 0; a < O; ++a) {
-                T t[ND];
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    T c[ND];
-                    load_cp<T, ND>(w0 + ((long long)a * cs[0] + k) * ND, c);
-#pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[1][k];
-                }
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < O; ++a) {
-                T s[ND];
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) s[dd] = T(0);
-#pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    T t[ND];
-#pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
-                    const T *__restrict__ row = w0 + ((long long)a * cs[0] + (long long)k * cs[1]) * ND;
-#pragma unroll
-                    for (int m = 0; m < O; ++m) {
-                        T c[ND];
-                        load_cp<T, ND>(row + m * ND, c);
-#pragma unroll
-                        for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[2][m];
-                    }
-#pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) s[dd] += t[dd] * b[1][k];
-                }
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) r[dd] += s[dd] * b[0][a];
-            }
-        }
+        window_contract<T, NIND, O, ND, MIXED>(w0, cs[0], NIND == 3 ? cs[1] : 1, pad, b, r);
         BinOut<T, ND> o;
 #pragma unroll
         for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? r[k < ND ? k : 0] : T(0);
         tmp[p] = o;
-    }
-}
-
-// Window contraction on a control-point-major table with strides s0 / s1 (control points) of the
-// first / second variable; the last variable is contiguous.  Same operation order as eval_gather.
-template <typename T, int NIND, int O, int ND, typename CP>
-__device__ __forceinline__ void window_contract(CP w0, int s0, int s1, const T (&b)[NIND][O], T (&r)[ND])
-{
-#pragma unroll
-    for (int dd = 0; dd < ND; ++dd) r[dd] = T(0);
-    if constexpr (NIND == 2) {
-#pragma unroll
-        for (int a = 0; a < O; ++a) {
-            T t[ND];
-#pragma unroll
-            for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
-#pragma unroll
-            for (int k = 0; k < O; ++k) {
-                T c[ND];
-                load_cp<T, ND>(w0 + (a * s0 + k) * ND, c);
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[1][k];
-            }
-#pragma unroll
-            for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < O; ++a) {
-            T s[ND];
-#pragma unroll
-            for (int dd = 0; dd < ND; ++dd) s[dd] = T(0);
-#pragma unroll
-            for (int k = 0; k < O; ++k) {
-                T t[ND];
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
-                CP row = w0 + (a * s0 + k * s1) * ND;
-#pragma unroll
-                for (int m = 0; m < O; ++m) {
-                    T c[ND];
-                    load_cp<T, ND>(row + m * ND, c);
-#pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[2][m];
-                }
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) s[dd] += t[dd] * b[1][k];
-            }
-#pragma unroll
-            for (int dd = 0; dd < ND; ++dd) r[dd] += s[dd] * b[0][a];
-        }
     }
 }
 
@@ -300,7 +275,7 @@ __device__ __forceinline__ void window_contract(CP w0, int s0, int s1, const T (
 // what bounds it; the bundle is read from L2 once per cell and workgroup instead and the windows
 // come from LDS (256 B/clk/CU).  A workgroup owns a contiguous slot range and goes through the
 // cells that overlap it.  LDS: [axis tables][bundle]
-template <typename T, int NIND, int O, int ND>
+template <typename T, int NIND, int O, int ND, bool MIXED>
 __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                        const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                        const BinRec<T, NIND> *__restrict__ rec, const long long N,
@@ -324,7 +299,10 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
     }
     __syncthreads();
     const int ncl = d.ncoef[NIND - 1];                       // control points per row (last variable)
-    const int S0 = d.ncoef[0] - O + 1, S1 = d.ncoef[1] - O + 1;
+    const int S0 = d.ncoef[0] - d.order[0] + 1, S1 = d.ncoef[1] - d.order[1] + 1;
+    int pad[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) pad[iv] = O - d.order[iv];
     const int cs0 = NIND == 3 ? d.ncoef[1] * d.ncoef[2] : d.ncoef[1];   // table strides (control points)
     const int cs1 = NIND == 3 ? d.ncoef[2] : 1;
     for (int c = s_first; c < bp.cells && lo < hi; ++c) {
@@ -334,8 +312,8 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
         if (sl >= sh) continue;
         // rows of this cell
         const int q0 = (c / bp.n1) << bp.sh0, q1 = NIND == 3 ? (c % bp.n1) << bp.sh1 : 0;
-        const int n0 = min(1 << bp.sh0, S0 - q0) + O - 1;
-        const int n1 = NIND == 3 ? min(1 << bp.sh1, S1 - q1) + O - 1 : 1;
+        const int n0 = min(1 << bp.sh0, S0 - q0) + d.order[0] - 1;
+        const int n1 = NIND == 3 ? min(1 << bp.sh1, S1 - q1) + d.order[1] - 1 : 1;
         const int rowlen = ncl * ND;                         // elements per row
         __syncthreads();                                     // previous cell's readers are done
         for (int r = threadIdx.x / 64; r < n0 * n1; r += blockDim.x / 64) {
@@ -354,14 +332,16 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
             for (int iv = 0; iv < NIND; ++iv) {
                 const T u = rc.v[iv];
                 const T *tab = stab + d.off[iv];
-                ix[iv] = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u) - O;
-                basis_fixed<T, O>(tab, d.nk[iv], ix[iv] + O, u, wrt.w[iv], b[iv]);
+                const int sp = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
+                if constexpr (MIXED) basis_bounded<T, O>(tab, d.nk[iv], d.order[iv], sp, u, wrt.w[iv], b[iv]);
+                else basis_fixed<T, O>(tab, d.nk[iv], sp, u, wrt.w[iv], b[iv]);
+                ix[iv] = sp - O;                               // right-aligned window start (may precede the bundle: padded)
             }
             int base;
             if constexpr (NIND == 3) base = (ix[0] - q0) * ls0 + (ix[1] - q1) * ls1 + ix[2];
             else base = (ix[0] - q0) * ls0 + ix[1];
             T r[ND];
-            window_contract<T, NIND, O, ND>(bun + (size_t)base * ND, ls0, ls1, b, r);
+            window_contract<T, NIND, O, ND, MIXED>(bun + (long long)base * ND, ls0, ls1, pad, b, r);
             BinOut<T, ND> o;
 #pragma unroll
             for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? r[k < ND ? k : 0] : T(0);

@@ -100,6 +100,44 @@ __device__ __forceinline__ void basis_value_and_d1(KP tab, int nk, int ix, T u, 
     }
 }
 
+// Run-time order <= OMAX with statically indexed registers (mixed-order splines, eval_mixed): the
+// recursion of basis_fixed on an array of OMAX entries, RIGHT aligned - r[OMAX - order + k]
+// multiplies coefficient ix - order + k, i.e. r[m] multiplies coefficient ix - OMAX + m, and
+// r[m] = 0 for m < OMAX - order.  Levels beyond the variable's own order are skipped by a
+// wave-uniform test (order and wrt are kernel arguments).
+template <typename T, int OMAX, typename KP>
+__device__ __forceinline__ void basis_bounded(KP tab, int nk, int order, int ix, T u, int wrt, T (&r)[OMAX])
+{
+#pragma unroll
+    for (int k = 0; k < OMAX; ++k) r[k] = T(0);
+    if (wrt >= order) return;
+    r[OMAX - 1] = T(1);
+#pragma unroll
+    for (int degree = 1; degree < OMAX; ++degree) {
+        if (degree < order) {
+            if (degree < order - wrt) {
+#pragma unroll
+                for (int j = 0; j < degree; ++j) {
+                    const int i = ix - degree + j;
+                    const int bi = OMAX - degree + j;
+                    const T alpha = (u - tab[i]) * tab[degree * nk + i];
+                    r[bi - 1] += (T(1) - alpha) * r[bi];
+                    r[bi] *= alpha;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < degree; ++j) {
+                    const int i = ix - degree + j;
+                    const int bi = OMAX - degree + j;
+                    const T alpha = T(degree) * tab[degree * nk + i];
+                    r[bi - 1] -= alpha * r[bi];
+                    r[bi] *= alpha;
+                }
+            }
+        }
+    }
+}
+
 // Same recursion for a run-time order (generic fallback, batched bspline_values).
 // b lives in private memory: this path trades speed for generality.
 template <typename T>

@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_cp(const T *__restrict__ p, T (&v)[ND])
 
 // aos: control-point-major coefficients, element (i0, .., i_last, dep) at
 // ((i0 * nc1 + i1) * nc2 + i2) * ND + dep.   out[dep * ostride + n]
-template <typename T, int NIND, int O, int ND>
+template <typename T, int NIND, int O, int ND, bool MIXED>
 __global__ __launch_bounds__(256) void eval_gather(const Desc<T> d, const T *__restrict__ gtab,
                                                    const T *__restrict__ aos, const Params<T> prm,
                                                    const long long N, T *__restrict__ out, const long long ostride,
@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256) void eval_gather(const Desc<T> d, const T *__r
     cs[NIND - 1] = 1;
 #pragma unroll
     for (int iv = NIND - 2; iv >= 0; --iv) cs[iv] = cs[iv + 1] * d.ncoef[iv + 1];
+    // O is the LARGEST order of the spline; a variable of lower order has its basis right aligned
+    // in the O slots (basis_bounded) and its first O - order window entries are neither weighted
+    // nor loaded (wave-uniform tests: the orders are kernel arguments).  MIXED = false (one common
+    // order) compiles all of that out.
+    int pad[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) pad[iv] = O - d.order[iv];
 
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
@@ -62,9 +69,10 @@ __global__ __launch_bounds__(256) void eval_gather(const Desc<T> d, const T *__r
             const T u = prm.p[iv][n];
             outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
             const T *tab = stab + d.off[iv];
-            const int ix = find_span<T>(tab, O, d.ncoef[iv], d.steps[iv], u);
-            basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
-            base += (ix - O) * cs[iv];
+            const int ix = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
+            if constexpr (MIXED) basis_bounded<T, O>(tab, d.nk[iv], d.order[iv], ix, u, wrt.w[iv], b[iv]);
+            else basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
+            base += (ix - O) * cs[iv];                        // right-aligned window, see the kernel comment
         }
         if (outside) record_bad(bad, n);
         const T *__restrict__ w0 = aos + (long long)base * ND;
@@ -74,51 +82,63 @@ __global__ __launch_bounds__(256) void eval_gather(const Desc<T> d, const T *__r
         if constexpr (NIND == 1) {
 #pragma unroll
             for (int k = 0; k < O; ++k) {
-                T c[ND];
-                load_cp<T, ND>(w0 + k * ND, c);
+                if (!MIXED || k >= pad[0]) {
+                    T c[ND];
+                    load_cp<T, ND>(w0 + k * ND, c);
 #pragma unroll
-                for (int dd = 0; dd < ND; ++dd) r[dd] += c[dd] * b[0][k];
+                    for (int dd = 0; dd < ND; ++dd) r[dd] += c[dd] * b[0][k];
+                }
             }
         } else if constexpr (NIND == 2) {
 #pragma unroll
             for (int a = 0; a < O; ++a) {
-                T t[ND];
+                if (!MIXED || a >= pad[0]) {
+                    T t[ND];
 #pragma unroll
-                for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
+                    for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
 #pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    T c[ND];
-                    load_cp<T, ND>(w0 + ((long long)a * cs[0] + k) * ND, c);
+                    for (int k = 0; k < O; ++k) {
+                        if (!MIXED || k >= pad[1]) {
+                            T c[ND];
+                            load_cp<T, ND>(w0 + ((long long)a * cs[0] + k) * ND, c);
 #pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[1][k];
+                            for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[1][k];
+                        }
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
                 }
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
             }
         } else {
 #pragma unroll
             for (int a = 0; a < O; ++a) {
-                T s[ND];
+                if (!MIXED || a >= pad[0]) {
+                    T s[ND];
 #pragma unroll
-                for (int dd = 0; dd < ND; ++dd) s[dd] = T(0);
+                    for (int dd = 0; dd < ND; ++dd) s[dd] = T(0);
 #pragma unroll
-                for (int k = 0; k < O; ++k) {
-                    T t[ND];
+                    for (int k = 0; k < O; ++k) {
+                        if (!MIXED || k >= pad[1]) {
+                            T t[ND];
 #pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
-                    const T *__restrict__ row = w0 + ((long long)a * cs[0] + (long long)k * cs[1]) * ND;
+                            for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
+                            const T *__restrict__ row = w0 + ((long long)a * cs[0] + (long long)k * cs[1]) * ND;
 #pragma unroll
-                    for (int m = 0; m < O; ++m) {
-                        T c[ND];
-                        load_cp<T, ND>(row + m * ND, c);
+                            for (int m = 0; m < O; ++m) {
+                                if (!MIXED || m >= pad[2]) {
+                                    T c[ND];
+                                    load_cp<T, ND>(row + m * ND, c);
 #pragma unroll
-                        for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[2][m];
+                                    for (int dd = 0; dd < ND; ++dd) t[dd] += c[dd] * b[2][m];
+                                }
+                            }
+#pragma unroll
+                            for (int dd = 0; dd < ND; ++dd) s[dd] += t[dd] * b[1][k];
+                        }
                     }
 #pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) s[dd] += t[dd] * b[1][k];
+                    for (int dd = 0; dd < ND; ++dd) r[dd] += s[dd] * b[0][a];
                 }
-#pragma unroll
-                for (int dd = 0; dd < ND; ++dd) r[dd] += s[dd] * b[0][a];
             }
         }
 #pragma unroll

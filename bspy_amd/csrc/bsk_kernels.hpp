@@ -70,6 +70,86 @@ __global__ __launch_bounds__(BLOCK_MAX) void eval_fixed(const Desc<T> d, const T
 }
 
 // ---------------------------------------------------------------------------------
+// evaluate / derivative, variables of DIFFERENT orders (CAD surfaces are often order (2, k) or
+// (3, k); the reference's fixture examples/TomsNasty.json is order (4, 5)): every variable is run
+// as order OMAX = max(order) with right-aligned basis arrays (basis_bounded) - the window starts at
+// ix - OMAX and its first OMAX - order entries per variable carry weight zero and are not loaded.
+// Same structure as eval_fixed otherwise.  out[d * ostride + n]
+// ---------------------------------------------------------------------------------
+template <typename T, int NIND, int OMAX, bool LDSC>
+__global__ __launch_bounds__(BLOCK_MAX) void eval_mixed(const Desc<T> d, const T *__restrict__ gtab,
+                                                        const T *__restrict__ gcoef, const Params<T> prm,
+                                                        const long long N, T *__restrict__ out,
+                                                        const long long ostride, const Wrt wrt,
+                                                        unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *stab = reinterpret_cast<T *>(smem);
+    T *scoef = stab + ((d.tab_len + 1) & ~1);
+    stage_tables(stab, scoef, gtab, d.tab_len, gcoef, d.coef_len, LDSC);
+    int pad[NIND];                                            // leading zero-weight entries per variable
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) pad[iv] = OMAX - d.order[iv];
+    const int s0 = NIND >= 2 ? d.cstride[1] : 0, s1 = NIND >= 3 ? d.cstride[2] : 0;
+
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T b[NIND][OMAX];
+        int base = 0;
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            const T u = prm.p[iv][n];
+            outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
+            const T *tab = stab + d.off[iv];
+            const int ix = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
+            basis_bounded<T, OMAX>(tab, d.nk[iv], d.order[iv], ix, u, wrt.w[iv], b[iv]);
+            base += (ix - OMAX) * d.cstride[iv + 1];          // may point before the table: padded entries are never read
+        }
+        if (outside) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            const T *c = (LDSC ? scoef : gcoef) + dep * d.cstride[0] + base;
+            T r = T(0);
+            if constexpr (NIND == 1) {
+#pragma unroll
+                for (int a = 0; a < OMAX; ++a)
+                    if (a >= pad[0]) r += c[a] * b[0][a];
+            } else if constexpr (NIND == 2) {
+#pragma unroll
+                for (int a = 0; a < OMAX; ++a) {
+                    if (a >= pad[0]) {
+                        T t = T(0);
+#pragma unroll
+                        for (int k = 0; k < OMAX; ++k)
+                            if (k >= pad[1]) t += c[a * s0 + k] * b[1][k];
+                        r += t * b[0][a];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < OMAX; ++a) {
+                    if (a >= pad[0]) {
+                        T ta = T(0);
+#pragma unroll
+                        for (int k = 0; k < OMAX; ++k) {
+                            if (k >= pad[1]) {
+                                T t = T(0);
+#pragma unroll
+                                for (int m = 0; m < OMAX; ++m)
+                                    if (m >= pad[2]) t += c[a * s0 + k * s1 + m] * b[2][m];
+                                ta += t * b[1][k];
+                            }
+                        }
+                        r += ta * b[0][a];
+                    }
+                }
+            }
+            nt_store(&out[dep * ostride + n], r);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // fused jacobian: every first partial derivative from one span search and one
 // recursion per variable, coefficients read once.  out[(dep * NIND + j) * N + n]
 // ---------------------------------------------------------------------------------

@@ -450,6 +450,9 @@ def test_kernel_variants(variant, golden_parity, monkeypatch):
     (3, 1, (3, 3, 3), (50, 40, 30), np.float64),  # fp64 volume: 32-byte records
     (3, 4, (5, 5, 5), (40, 40, 40), np.float32),  # cfg5 shape
     (3, 3, (4, 4, 4), (36, 30, 44), np.float64),  # nDep 3 fp64
+    (2, 3, (4, 5), (900, 11), np.float64),        # mixed orders: the shape of the reference's examples/TomsNasty.json
+    (3, 2, (3, 5, 2), (40, 50, 30), np.float64),  # mixed orders, three variables
+    (2, 4, (2, 6), (400, 300), np.float32),       # orders 2 and 6
 ])
 def test_large_batches_in_cell_order(shape, monkeypatch):
     """Batches of >= 2^18 points on L2-resident tables are counting-sorted by the cell of the first
@@ -494,6 +497,9 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
     (2, 4, (3, 3), (300, 300), np.float32),       # 1.4 MB, nDep 4 (one 16-byte load per control point)
     (3, 1, (3, 3, 3), (50, 40, 30), np.float64),  # 480 KB volume, nDep 1
     (3, 4, (5, 5, 5), (40, 40, 40), np.float32),  # cfg5 shape
+    (2, 3, (4, 5), (900, 11), np.float64),        # mixed orders (TomsNasty shape): right-aligned windows at the largest order
+    (3, 2, (3, 5, 2), (40, 50, 30), np.float64),
+    (2, 1, (1, 4), (5000, 40), np.float64),       # order 1 beside order 4
 ])
 def test_large_tables_gathered_from_l2(shape):
     """Tables that do not fit in LDS run on the control-point-major gather kernel."""
