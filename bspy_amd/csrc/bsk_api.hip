@@ -1389,18 +1389,23 @@ static bsk_status run_grid(bsk_spline s, const int *wrt, const void *const *grid
     const T *coef = static_cast<const T *>(s->coef);
     bool launched = false;
     const size_t rowc_bytes = sizeof(T) * (size_t)s->nDep * (size_t)(s->nInd == 2 ? s->ncoef[1] : 0);
-    if (s->nInd == 2 && s->same_order && s->order[0] <= 6 && rowc_bytes <= 48 * 1024 && g.n[1] >= 64 && s->variant != 1) {
+    const int omax2 = s->nInd == 2 ? std::max(s->order[0], s->order[1]) : 0;
+    if (s->nInd == 2 && omax2 <= 6 && rowc_bytes <= 48 * 1024 && g.n[1] >= 64 && s->variant != 1) {
         // row-factored surface grid
         constexpr long long VEC = 16 / (long long)sizeof(T);
         const int vec_ok = (g.n[1] % VEC == 0) && ((reinterpret_cast<uintptr_t>(dout) & 15) == 0) ? 1 : 0;
         const int gridx = (int)std::max<long long>(1, std::min<long long>(g.n[0], (long long)s->num_cu * 8));
 #define GRID_ROWS(O)                                                                                           \
     case O:                                                                                                    \
-        hipLaunchKernelGGL((grid_rows<T, O>), dim3(gridx), dim3(256), rowc_bytes, st, d, coef, g, ixs, rows,   \
-                           outside, dout, s->bad, vec_ok);                                                     \
+        if (s->same_order)                                                                                     \
+            hipLaunchKernelGGL((grid_rows<T, O, false>), dim3(gridx), dim3(256), rowc_bytes, st, d, coef, g, ixs, rows, \
+                               outside, dout, s->bad, vec_ok);                                                 \
+        else                                                                                                   \
+            hipLaunchKernelGGL((grid_rows<T, O, true>), dim3(gridx), dim3(256), rowc_bytes, st, d, coef, g, ixs, rows,  \
+                               outside, dout, s->bad, vec_ok);                                                 \
         launched = true;                                                                                       \
         break;
-        switch (s->order[0]) {
+        switch (omax2) {
             GRID_ROWS(1) GRID_ROWS(2) GRID_ROWS(3) GRID_ROWS(4) GRID_ROWS(5) GRID_ROWS(6)
             default: break;
         }

@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256) void grid_surface(const Desc<T> d, const T *__
 // neighbouring lanes share (broadcast).  Lanes own VEC = 16 / sizeof(T) consecutive columns and
 // store 16 bytes per dependent variable when the rows are aligned.  The kernel is bound by its
 // stores (12 B fp32 / 24 B fp64 per point for nDep 3).  out[dep * total + i0 * n1 + i1]
-template <typename T, int O>
+// MIXED: the two variables have different orders o0, o1 <= O (O = the larger): loops run to O with
+// wave-uniform tests; one common order compiles them out.
+template <typename T, int O, bool MIXED>
 __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__restrict__ gcoef, const GridDims g,
                                                  const int *__restrict__ ixs, const T *__restrict__ rows,
                                                  const unsigned char *__restrict__ outside, T *__restrict__ out,
@@ -451,19 +453,21 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
     constexpr int VEC = 16 / (int)sizeof(T);
     const long long n1 = g.n[1], total = g.n[0] * g.n[1];
     const int nc1 = d.ncoef[1], s0 = d.cstride[1];
+    const int o0 = MIXED ? d.order[0] : O, o1 = MIXED ? d.order[1] : O;
     for (long long i0 = blockIdx.x; i0 < g.n[0]; i0 += gridDim.x) {
         const int ix0 = ixs[g.goff[0] + i0];
         const bool bad0 = outside[g.goff[0] + i0] != 0;
         T b0[O];
 #pragma unroll
-        for (int a = 0; a < O; ++a) b0[a] = rows[g.roff[0] + i0 * O + a];
+        for (int a = 0; a < O; ++a) b0[a] = (!MIXED || a < o0) ? rows[g.roff[0] + i0 * o0 + a] : T(0);
         __syncthreads();                                       // the previous row's readers are done
         for (int e = threadIdx.x; e < d.nDep * nc1; e += blockDim.x) {
             const int dep = e / nc1, c = e - dep * nc1;
-            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - O) * s0 + c;
+            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - o0) * s0 + c;
             T acc = T(0);
 #pragma unroll
-            for (int a = 0; a < O; ++a) acc += b0[a] * col[a * s0];
+            for (int a = 0; a < O; ++a)
+                if (!MIXED || a < o0) acc += b0[a] * col[a * s0];
             rowc[e] = acc;
         }
         __syncthreads();
@@ -474,9 +478,9 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
                 bool anybad = bad0;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    ix1[v] = ixs[g.goff[1] + c0 + v] - O;
+                    ix1[v] = ixs[g.goff[1] + c0 + v] - o1;
 #pragma unroll
-                    for (int k = 0; k < O; ++k) b1[v][k] = rows[g.roff[1] + (c0 + v) * O + k];
+                    for (int k = 0; k < O; ++k) b1[v][k] = (!MIXED || k < o1) ? rows[g.roff[1] + (c0 + v) * o1 + k] : T(0);
                     anybad |= outside[g.goff[1] + c0 + v] != 0;
                 }
                 if (anybad) {
@@ -491,7 +495,8 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
                         const T *rc = rowc + dep * nc1 + ix1[v];
                         T acc = T(0);
 #pragma unroll
-                        for (int k = 0; k < O; ++k) acc += rc[k] * b1[v][k];
+                        for (int k = 0; k < O; ++k)
+                            if (!MIXED || k < o1) acc += rc[k] * b1[v][k];
                         res[v] = acc;
                     }
                     T *o = out + dep * total + i0 * n1 + c0;
@@ -505,16 +510,17 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
             }
         } else {
             for (long long i1 = threadIdx.x; i1 < n1; i1 += blockDim.x) {
-                const int ix1 = ixs[g.goff[1] + i1] - O;
+                const int ix1 = ixs[g.goff[1] + i1] - o1;
                 T b1[O];
 #pragma unroll
-                for (int k = 0; k < O; ++k) b1[k] = rows[g.roff[1] + i1 * O + k];
+                for (int k = 0; k < O; ++k) b1[k] = (!MIXED || k < o1) ? rows[g.roff[1] + i1 * o1 + k] : T(0);
                 if (bad0 | (outside[g.goff[1] + i1] != 0)) record_bad(bad, i0 * n1 + i1);
                 for (int dep = 0; dep < d.nDep; ++dep) {
                     const T *rc = rowc + dep * nc1 + ix1;
                     T acc = T(0);
 #pragma unroll
-                    for (int k = 0; k < O; ++k) acc += rc[k] * b1[k];
+                    for (int k = 0; k < O; ++k)
+                        if (!MIXED || k < o1) acc += rc[k] * b1[k];
                     __builtin_nontemporal_store(acc, &out[dep * total + i0 * n1 + i1]);
                 }
             }

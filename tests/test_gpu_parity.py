@@ -203,6 +203,18 @@ def test_grid_broadcast_matches_flat():
         mesh = np.meshgrid(*axes, indexing="ij")
         f = t.evaluate([m.ravel() for m in mesh]).reshape(g.shape)
         assert np.abs(g - f).max() <= 1e-12 * _scale(f)
+    # mixed orders on the row-factored grid kernel (vector and scalar store paths), order 7 on the generic one
+    for name in ("surface_o2x6_d1", "surface_o1x4_d2", "surface_o3x4", "surface_f64knots_f32coefs", "surface_o7x3_d6"):
+        c = CASES[name]
+        t = _tables(c)
+        dom = [(k[o - 1], k[nc]) for k, o, nc in zip(c.knots, c.order, c.nCoef)]
+        for n1 in (128, 77):
+            axes = [np.linspace(dom[0][0], dom[0][1], 48), np.linspace(dom[1][0], dom[1][1], n1)]
+            for w in ([0, 0], [1, 1]):
+                g = t.evaluate_grid(axes, w)
+                mesh = np.meshgrid(*axes, indexing="ij")
+                f = t.evaluate([m.ravel() for m in mesh], w).reshape(g.shape)
+                assert np.abs(g - f).max() <= 1e-12 * _scale(f), (name, n1, w)
     # out-of-domain value on a grid: first offender in broadcast order
     u2 = u.copy()
     u2[5] = 99.0
