@@ -427,7 +427,8 @@ static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T>
     return BSK_OK;
 }
 
-// Variables of different orders, all <= 6, nInd <= 3: eval_mixed at OMAX = the largest order.
+// Variables of different orders (or one order beyond the fixed-order kernels): eval_mixed at OMAX = the
+// largest order - surfaces up to order 8, volumes up to 6, curves 9..12.
 template <typename T, int NIND, int OMAX>
 static bsk_status launch_eval_mixed(bsk_spline s, const Plan &p, const Params<T> &prm, long long n, T *out,
                                     long long ostride, const Wrt &w, hipStream_t st)
@@ -854,10 +855,11 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         else { BSK_ORDER_SWITCH(3, CALL_EVAL) }
 #undef CALL_EVAL
     }
-    if (!s->same_order && s->nInd >= 1 && s->nInd <= 3 && s->variant != 1) {
+    // What is left: variables of different orders, or orders beyond the fixed-order kernels.
+    if (s->nInd >= 1 && s->nInd <= 3 && s->variant != 1) {
         int omax = 0;
         for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
-        if (omax >= 2 && omax <= 6 && s->coef_aos) {
+        if (!s->same_order && omax >= 2 && omax <= 6 && s->coef_aos) {
             // table too large for LDS: control-point-major gather / cell-order pipeline at O = omax
 #define CALL_GATHER_M(NIND)                                                                       \
     switch (omax) {                                                                               \
@@ -871,20 +873,17 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
             else if (s->nInd == 3) { CALL_GATHER_M(3) }
 #undef CALL_GATHER_M
         }
-        if (omax >= 2 && omax <= 6) {
-            const Plan p = make_plan<T>(s, n);
-#define CALL_MIXED(NIND)                                                                          \
-    switch (omax) {                                                                               \
-        case 2: return launch_eval_mixed<T, NIND, 2>(s, p, prm, n, out, ostride, w, st);          \
-        case 3: return launch_eval_mixed<T, NIND, 3>(s, p, prm, n, out, ostride, w, st);          \
-        case 4: return launch_eval_mixed<T, NIND, 4>(s, p, prm, n, out, ostride, w, st);          \
-        case 5: return launch_eval_mixed<T, NIND, 5>(s, p, prm, n, out, ostride, w, st);          \
-        default: return launch_eval_mixed<T, NIND, 6>(s, p, prm, n, out, ostride, w, st);         \
-    }
-            if (s->nInd == 2) { CALL_MIXED(2) }
-            else if (s->nInd == 3) { CALL_MIXED(3) }
-#undef CALL_MIXED
+        // eval_mixed: surfaces up to order 8, volumes up to 6, curves up to 12
+        const Plan p = make_plan<T>(s, n);
+#define MIXED_CASE(NIND, OM) case OM: return launch_eval_mixed<T, NIND, OM>(s, p, prm, n, out, ostride, w, st);
+        if (s->nInd == 1 && omax >= 9 && omax <= 12) {
+            switch (omax) { MIXED_CASE(1, 9) MIXED_CASE(1, 10) MIXED_CASE(1, 11) MIXED_CASE(1, 12) default: break; }
+        } else if (s->nInd == 2 && omax >= 2 && omax <= 8) {
+            switch (omax) { MIXED_CASE(2, 2) MIXED_CASE(2, 3) MIXED_CASE(2, 4) MIXED_CASE(2, 5) MIXED_CASE(2, 6) MIXED_CASE(2, 7) MIXED_CASE(2, 8) default: break; }
+        } else if (s->nInd == 3 && omax >= 2 && omax <= 6) {
+            switch (omax) { MIXED_CASE(3, 2) MIXED_CASE(3, 3) MIXED_CASE(3, 4) MIXED_CASE(3, 5) MIXED_CASE(3, 6) default: break; }
         }
+#undef MIXED_CASE
     }
     return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
 }

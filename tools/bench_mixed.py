@@ -12,7 +12,7 @@ def timed(f, steps=10):
 n = 10_000_000
 rng = np.random.default_rng(3)
 for name, order, ncoef, ndep in (("surface 3x4 20x20", (3, 4), (20, 20), 3), ("surface 4x5 900x11 (TomsNasty shape)", (4, 5), (900, 11), 3),
-                                 ("surface 4x4 20x20 (same order)", (4, 4), (20, 20), 3), ("curve o9", (9,), (30,), 2), ("4 variables o3", (3, 3, 3, 3), (6, 6, 6, 6), 2)):
+                                 ("surface 4x4 20x20 (same order)", (4, 4), (20, 20), 3), ("curve o9", (9,), (30,), 2), ("curve o12", (12,), (30,), 2), ("surface 7x3 11x20", (7, 3), (11, 20), 3), ("surface 8x8 20x20", (8, 8), (20, 20), 3), ("4 variables o3", (3, 3, 3, 3), (6, 6, 6, 6), 2)):
     knots = [cases.clamped_uniform_knots(o, c) for o, c in zip(order, ncoef)]
     coefs = rng.standard_normal((ndep, *ncoef))
     t = bspy_amd.DeviceSpline(order, ncoef, knots, coefs)
