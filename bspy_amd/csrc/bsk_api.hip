@@ -977,7 +977,6 @@ static long long small_call_points()
     static const long long v = getenv("BSK_SMALL_POINTS") ? atoll(getenv("BSK_SMALL_POINTS")) : 65536;
     return v;
 }
-#define SMALL_CALL_POINTS small_call_points()
 
 __global__ void publish_bad(unsigned long long *bad, unsigned long long *slot)
 {
@@ -1045,7 +1044,6 @@ static long long host_chunk_points()
     }();
     return v;
 }
-#define HOST_CHUNK host_chunk_points()
 
 template <typename T>
 static bsk_status run_points(bsk_spline s, bool jac, const int *wrt, const void *const *uvw, long long n, bsk_mem mem,
@@ -1066,13 +1064,13 @@ static bsk_status run_points(bsk_spline s, bool jac, const int *wrt, const void 
                    : dispatch_eval<T>(s, prm, n, static_cast<T *>(out), n, w, st);
     }
 
-    if (n <= SMALL_CALL_POINTS)
+    if (n <= small_call_points())
         return run_small<T>(s, uvw, n, outs, out, st, first_bad, [&](const Params<T> &prm, T *dout) {
             return jac ? dispatch_jac<T>(s, prm, n, dout, st) : dispatch_eval<T>(s, prm, n, dout, n, w, st);
         });
 
     // host buffers: stage chunk by chunk
-    const long long chunk = std::min(n, HOST_CHUNK);
+    const long long chunk = std::min(n, host_chunk_points());
     HIPCHK(s->in_ws.reserve(sizeof(T) * (size_t)chunk * s->nInd));
     HIPCHK(s->out_ws.reserve(sizeof(T) * (size_t)chunk * outs));
     T *din = static_cast<T *>(s->in_ws.p);
@@ -1146,10 +1144,10 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
     const int big = std::max(s->nInd, s->nDep);
     if (first_bad) *first_bad = -1;
     if (n == 0) return BSK_OK;
-    const long long chunk = mem == BSK_HOST ? std::min(n, HOST_CHUNK) : n;
+    const long long chunk = mem == BSK_HOST ? std::min(n, host_chunk_points()) : n;
     // jacobian workspace (device) for one chunk, unless the normal is fused into the jacobian kernel
     const bool fused = s->nDep == 3 && rowrot_applies<T>(s);
-    if (mem == BSK_HOST && n <= SMALL_CALL_POINTS) {
+    if (mem == BSK_HOST && n <= small_call_points()) {
         if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)n * s->nDep * s->nInd));
         return run_small<T>(s, uvw, n, big, out, st, first_bad, [&](const Params<T> &prm, T *dout) -> bsk_status {
             if (fused) return launch_jac_rowrot<T, true>(s, prm, n, dout, normalize, negate, st);
@@ -1240,7 +1238,7 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
     if (n == 0) return BSK_OK;
     const bool surface = s->nInd == 2;
     const int nbuf = surface ? 6 : 2;                    // derivative buffers (+ normal) of nDep rows each
-    const long long chunk = std::min<long long>(n, mem == BSK_HOST ? HOST_CHUNK : (1ll << 22));
+    const long long chunk = std::min<long long>(n, mem == BSK_HOST ? host_chunk_points() : (1ll << 22));
     DevBuf work;                                         // derivative workspace (freed on return)
     HIPCHK(work.reserve(sizeof(T) * (size_t)chunk * s->nDep * nbuf));
     struct Guard { DevBuf &b; ~Guard() { b.release(); } } guard{work};
