@@ -427,6 +427,10 @@ static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T>
     return BSK_OK;
 }
 
+template <typename T>
+static bsk_status launch_eval_generic(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                      const Wrt &w, hipStream_t st);
+
 // Variables of different orders (or one order beyond the fixed-order kernels): eval_mixed at OMAX = the
 // largest order - surfaces up to order 8, volumes up to 6, curves 9..12.
 template <typename T, int NIND, int OMAX>
@@ -440,6 +444,10 @@ static bsk_status launch_eval_mixed(bsk_spline s, const Plan &p, const Params<T>
         HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, true>, p.lds_bytes));
         hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
+    } else if constexpr (NIND >= 4) {
+        // four and five variables: only the LDS-resident form is instantiated (build time); larger tables
+        // stay on the generic kernel
+        return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
     } else {
         HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, false>, p.lds_bytes));
         hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
@@ -856,7 +864,7 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
 #undef CALL_EVAL
     }
     // What is left: variables of different orders, or orders beyond the fixed-order kernels.
-    if (s->nInd >= 1 && s->nInd <= 3 && s->variant != 1) {
+    if (s->nInd >= 1 && s->nInd <= 5 && s->variant != 1) {
         int omax = 0;
         for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
         if (!s->same_order && omax >= 2 && omax <= 6 && s->coef_aos) {
@@ -873,7 +881,7 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
             else if (s->nInd == 3) { CALL_GATHER_M(3) }
 #undef CALL_GATHER_M
         }
-        // eval_mixed: surfaces up to order 8, volumes up to 6, curves up to 12
+        // eval_mixed: surfaces up to order 8, volumes up to 6, curves up to 12, four variables up to order 4, five up to 3
         const Plan p = make_plan<T>(s, n);
 #define MIXED_CASE(NIND, OM) case OM: return launch_eval_mixed<T, NIND, OM>(s, p, prm, n, out, ostride, w, st);
         if (s->nInd == 1 && omax >= 9 && omax <= 12) {
@@ -882,6 +890,10 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
             switch (omax) { MIXED_CASE(2, 2) MIXED_CASE(2, 3) MIXED_CASE(2, 4) MIXED_CASE(2, 5) MIXED_CASE(2, 6) MIXED_CASE(2, 7) MIXED_CASE(2, 8) default: break; }
         } else if (s->nInd == 3 && omax >= 2 && omax <= 6) {
             switch (omax) { MIXED_CASE(3, 2) MIXED_CASE(3, 3) MIXED_CASE(3, 4) MIXED_CASE(3, 5) MIXED_CASE(3, 6) default: break; }
+        } else if (s->nInd == 4 && omax >= 2 && omax <= 4) {
+            switch (omax) { MIXED_CASE(4, 2) MIXED_CASE(4, 3) MIXED_CASE(4, 4) default: break; }
+        } else if (s->nInd == 5 && omax >= 2 && omax <= 3) {
+            switch (omax) { MIXED_CASE(5, 2) MIXED_CASE(5, 3) default: break; }
         }
 #undef MIXED_CASE
     }

@@ -69,6 +69,24 @@ __global__ __launch_bounds__(BLOCK_MAX) void eval_fixed(const Desc<T> d, const T
     }
 }
 
+// Window contraction for eval_mixed, any number of variables: variable IV outermost, the last
+// variable innermost - the reference's `myCoefs @ bValues[iv]` from the last variable to the first
+// (bspy/_spline_evaluation.py:162-163).  Entries below pad[iv] carry weight zero and are not read.
+template <typename T, int NIND, int OMAX, int IV>
+__device__ __forceinline__ T mixed_contract(const T *c, const int (&cstride)[MAXI + 1], const int (&pad)[NIND],
+                                            const T (&b)[NIND][OMAX])
+{
+    if constexpr (IV == NIND) {
+        return *c;
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int a = 0; a < OMAX; ++a)
+            if (a >= pad[IV]) acc += mixed_contract<T, NIND, OMAX, IV + 1>(c + a * cstride[IV + 1], cstride, pad, b) * b[IV][a];
+        return acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // evaluate / derivative, variables of DIFFERENT orders (CAD surfaces are often order (2, k) or
 // (3, k); the reference's fixture examples/TomsNasty.json is order (4, 5)): every variable is run
@@ -90,7 +108,6 @@ __global__ __launch_bounds__(BLOCK_MAX) void eval_mixed(const Desc<T> d, const T
     int pad[NIND];                                            // leading zero-weight entries per variable
 #pragma unroll
     for (int iv = 0; iv < NIND; ++iv) pad[iv] = OMAX - d.order[iv];
-    const int s0 = NIND >= 2 ? d.cstride[1] : 0, s1 = NIND >= 3 ? d.cstride[2] : 0;
 
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
@@ -109,41 +126,7 @@ __global__ __launch_bounds__(BLOCK_MAX) void eval_mixed(const Desc<T> d, const T
         if (outside) record_bad(bad, n);
         for (int dep = 0; dep < d.nDep; ++dep) {
             const T *c = (LDSC ? scoef : gcoef) + dep * d.cstride[0] + base;
-            T r = T(0);
-            if constexpr (NIND == 1) {
-#pragma unroll
-                for (int a = 0; a < OMAX; ++a)
-                    if (a >= pad[0]) r += c[a] * b[0][a];
-            } else if constexpr (NIND == 2) {
-#pragma unroll
-                for (int a = 0; a < OMAX; ++a) {
-                    if (a >= pad[0]) {
-                        T t = T(0);
-#pragma unroll
-                        for (int k = 0; k < OMAX; ++k)
-                            if (k >= pad[1]) t += c[a * s0 + k] * b[1][k];
-                        r += t * b[0][a];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int a = 0; a < OMAX; ++a) {
-                    if (a >= pad[0]) {
-                        T ta = T(0);
-#pragma unroll
-                        for (int k = 0; k < OMAX; ++k) {
-                            if (k >= pad[1]) {
-                                T t = T(0);
-#pragma unroll
-                                for (int m = 0; m < OMAX; ++m)
-                                    if (m >= pad[2]) t += c[a * s0 + k * s1 + m] * b[2][m];
-                                ta += t * b[1][k];
-                            }
-                        }
-                        r += ta * b[0][a];
-                    }
-                }
-            }
+            const T r = mixed_contract<T, NIND, OMAX, 0>(c, d.cstride, pad, b);
             nt_store(&out[dep * ostride + n], r);
         }
     }
