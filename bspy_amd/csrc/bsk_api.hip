@@ -1249,7 +1249,8 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
     if (first_bad) *first_bad = -1;
     if (n == 0) return BSK_OK;
     const bool surface = s->nInd == 2;
-    const int nbuf = surface ? 6 : 2;                    // derivative buffers (+ normal) of nDep rows each
+    const bool fused = surface && s->nDep == 3 && rowrot_applies<T>(s);   // curv_rowrot: no intermediates at all
+    const int nbuf = fused ? 0 : (surface ? 6 : 2);      // derivative buffers (+ normal) of nDep rows each
     const long long chunk = std::min<long long>(n, mem == BSK_HOST ? host_chunk_points() : (1ll << 22));
     DevBuf work;                                         // derivative workspace (freed on return)
     HIPCHK(work.reserve(sizeof(T) * (size_t)chunk * s->nDep * nbuf));
@@ -1290,6 +1291,27 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
             if ((r = deriv(1, 0, w)) != BSK_OK) return r;
             if ((r = deriv(2, 0, w + one)) != BSK_OK) return r;
             hipLaunchKernelGGL((curvature_curve<T>), dim3(grid), dim3(block), 0, st, w, w + one, s->nDep, m, o);
+        } else if (fused) {
+            const Desc<T> &d = desc_of<T>(s);
+            const TileDesc<T> &tdr = tile_of<T>(s);
+            const size_t lds_rr = rowrot_lds_bytes<T>(s);
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));
+            const long long cmax = rr_chunk_points();
+            for (long long c0 = 0; c0 < m; c0 += cmax) {
+                const long long mm = std::min<long long>(m - c0, cmax);
+                const int g = (int)std::max<long long>(1, std::min<long long>((mm + TILE - 1) / TILE, (long long)s->num_cu * per_cu));
+                Params<T> cp = prm;
+                for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + c0;
+                if (s->order[0] == 4) {
+                    HIPCHK(allow_lds(curv_rowrot<T, 4>, lds_rr));
+                    hipLaunchKernelGGL((curv_rowrot<T, 4>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, static_cast<const T *>(s->tab),
+                                       s->lut, static_cast<const T *>(s->coef), cp, (unsigned)mm, c0, o + c0, s->bad);
+                } else {
+                    HIPCHK(allow_lds(curv_rowrot<T, 2>, lds_rr));
+                    hipLaunchKernelGGL((curv_rowrot<T, 2>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, static_cast<const T *>(s->tab),
+                                       s->lut, static_cast<const T *>(s->coef), cp, (unsigned)mm, c0, o + c0, s->bad);
+                }
+            }
         } else {
             if ((r = deriv(1, 0, w)) != BSK_OK) return r;
             if ((r = deriv(0, 1, w + one)) != BSK_OK) return r;

@@ -480,4 +480,175 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
     }
 }
 
+// curv_rowrot: Gaussian curvature of a surface in 3-D, fused (reference
+// bspy/_spline_evaluation.py:94-107): K = (L N - M^2) / (E G - F^2) with E, F, G from the tangents
+// S_u, S_v and L, M, N = S_uu . n, S_uv . n, S_vv . n, n the unit normal.  One kernel instead of
+// five derivative passes + normal + epilogue (8 B per point out instead of 144 B of intermediates):
+//   - one span search and one set of table reads per variable; the recursion is run for the
+//     value, first- and second-derivative bases on the same registers;
+//   - pass 1 over the three dependent variables reads each window once and forms S_u, S_v
+//     (as jac_rowrot), then E, F, G and the unit normal;
+//   - pass 2 reads the windows again, half a window (two rows) at a time to keep the register
+//     count down, and accumulates L, M, N.
+// Row rotation and the rotation-invariant tree as in eval_rowrot.  out[n]
+template <typename T, int O>
+__global__ __launch_bounds__(TILE) void curv_rowrot(const Desc<T> d, const TileDesc<T> td,
+                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                    const T *__restrict__ gcoef, const Params<T> prm,
+                                                    const unsigned N, const long long n0, T *__restrict__ out,
+                                                    unsigned long long *bad)
+{
+    static_assert(O == 2 || O == 4, "row rotation covers orders 2 and 4");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
+    const unsigned rec_a[2] = {(unsigned)(size_t)smem, (unsigned)(size_t)smem + (unsigned)d.nk[0] * rr_rec_bytes<T, O>()};
+    const unsigned lut_a = rec_a[0] + rec_bytes;
+    const unsigned coef_a = lut_a + rr_lut_bytes<T>(td.lut_len);
+    const int nc0 = d.ncoef[0], nc1 = d.ncoef[1];
+    const int rs = nc1 | 1;
+    const unsigned rstride = (unsigned)rs * (unsigned)sizeof(T);
+    const unsigned dstride = (unsigned)(nc0 * rs) * (unsigned)sizeof(T);
+    stage_image_rowrot<T, O>(smem, d, td, gtab, glut, gcoef, nc1, rs);
+    __syncthreads();
+    unsigned *s_rc = reinterpret_cast<unsigned *>(smem + rec_bytes + rr_lut_bytes<T>(td.lut_len) +
+                                                 (((unsigned)d.nDep * dstride + 15u) & ~15u)) + (threadIdx.x & ~63);
+    const int lane = threadIdx.x & 63;
+    const int steps = td.lut_steps[0] > td.lut_steps[1] ? td.lut_steps[0] : td.lut_steps[1];
+    const unsigned stride = gridDim.x * (unsigned)TILE;
+    unsigned n = ((threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64u + (unsigned)lane;
+    const T lo0 = d.lo[0], lo1 = d.lo[1], hi0 = d.hi[0], hi1 = d.hi[1];
+    const T *p0 = prm.p[0], *p1 = prm.p[1];
+    Wrt w0, w1, w2;
+    for (int iv = 0; iv < MAXI; ++iv) { w0.w[iv] = 0; w1.w[iv] = 1; w2.w[iv] = 2; }
+    T un[2] = {lo0, lo1};
+    if (n < N) { un[0] = rr_load(p0, n * (unsigned)sizeof(T)); un[1] = rr_load(p1, n * (unsigned)sizeof(T)); }
+    asm volatile("" : "+v"(un[0]), "+v"(un[1]));   // see eval_rowrot: no load pending at the loop header
+
+    for (; n < N; n += stride) {
+        const T u[2] = {un[0], un[1]};
+        const bool outside = (u[0] < lo0) | (u[0] > hi0) | (u[1] < lo1) | (u[1] > hi1);
+        {
+            const unsigned nn = min(n + stride, N - 1u) * (unsigned)sizeof(T);
+            un[0] = rr_load(p0, nn);
+            un[1] = rr_load(p1, nn);
+        }
+        if (outside) record_bad(bad, n0 + (long long)n);
+
+        int ix[2];
+        rr_find_spans<T, O, true>(rec_a, lut_a, d, td, steps, u, ix);
+        const int base = (int)__umul24((unsigned)(ix[0] - O), (unsigned)rs) + (ix[1] - O);
+        const int rank = rr_rank_request(base, s_rc, lane);
+        T b[2][O], db[2][O], ddb[2][O];
+        {
+            T kn[2][O], rc[2][O][O];
+            rr_issue_tables<T, O>(rec_a, ix, kn, rc);
+            // the same table values give the value, first- and second-derivative bases (the waits
+            // inside the second and third run find their reads complete)
+            bases_compute<T, 2, O, true, 0>(u, w0, kn, rc, b);
+            bases_compute<T, 2, O, true, 0>(u, w1, kn, rc, db);
+            bases_compute<T, 2, O, true, 0>(u, w2, kn, rc, ddb);
+        }
+        unsigned ra[O];
+        const int rho = rr_rows<T, O>(coef_a, base, rank, rstride, ra);
+        T b0r[O], db0r[O], ddb0r[O];
+        rotate_basis_values<T, O>(b[0], rho, b0r);
+        rotate_basis_values<T, O>(db[0], rho, db0r);
+        rotate_basis_values<T, O>(ddb[0], rho, ddb0r);
+
+        __builtin_amdgcn_s_setprio(3);
+        // ---- pass 1: tangents
+        T su[3], sv[3];
+#pragma unroll
+        for (int dep = 0; dep < 3; ++dep) {
+            T c[O][O];
+#pragma unroll
+            for (int a = 0; a < O; ++a) lds_issue_row<T, O>(ra[a], c[a]);
+            block_wait<0>(c);
+            T qu[O], qv[O];
+#pragma unroll
+            for (int a = 0; a < O; ++a) {
+                T t = T(0), tdv = T(0);
+#pragma unroll
+                for (int k = 0; k < O; ++k) { t += c[a][k] * b[1][k]; tdv += c[a][k] * db[1][k]; }
+                qu[a] = mul_rn<T>(t, db0r[a]);
+                qv[a] = mul_rn<T>(tdv, b0r[a]);
+            }
+            T du, dv;
+            if constexpr (O == 2) {
+                du = add_rn<T>(qu[0], qu[1]);
+                dv = add_rn<T>(qv[0], qv[1]);
+            } else {
+                du = add_rn<T>(add_rn<T>(qu[0], qu[2]), add_rn<T>(qu[1], qu[3]));
+                dv = add_rn<T>(add_rn<T>(qv[0], qv[2]), add_rn<T>(qv[1], qv[3]));
+            }
+            asm volatile("" : "+v"(du), "+v"(dv));
+            su[dep] = du;
+            sv[dep] = dv;
+#pragma unroll
+            for (int a = 0; a < O; ++a) ra[a] += dstride;
+        }
+        // first fundamental form and unit normal (cofactors of the tangent space, as in jac_rowrot)
+        T E = T(0), F = T(0), G = T(0);
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) { E += su[dd] * su[dd]; F += su[dd] * sv[dd]; G += sv[dd] * sv[dd]; }
+        T nrm[3];
+        {
+            T nx = su[1] * sv[2] - sv[1] * su[2];
+            T ny = -(su[0] * sv[2] - sv[0] * su[2]);
+            T nz = su[0] * sv[1] - sv[0] * su[1];
+            const T len = sqrt(nx * nx + ny * ny + nz * nz);
+            nrm[0] = nx / len; nrm[1] = ny / len; nrm[2] = nz / len;
+        }
+        asm volatile("" : "+v"(E), "+v"(F), "+v"(G), "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]));
+        // ---- pass 2: second fundamental form, two window rows at a time
+        T L = T(0), M = T(0), Nn = T(0);
+#pragma unroll
+        for (int a = 0; a < O; ++a) ra[a] -= 3u * dstride;
+#pragma unroll
+        for (int dep = 0; dep < 3; ++dep) {
+            T part[O / 2][3];                  // per half: (q_a + q_a') of S_uu, S_uv, S_vv
+#pragma unroll
+            for (int h = 0; h < O / 2; ++h) {
+                // rows h and h + O/2: the pairs the rotation-invariant tree adds first
+                T c[2][O];
+                lds_issue_row<T, O>(ra[h], c[0]);
+                lds_issue_row<T, O>(ra[h + O / 2], c[1]);
+                block_wait<0>(c);
+                T q[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int a = h + j * (O / 2);
+                    T t = T(0), tdv = T(0), tdd = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        t += c[j][k] * b[1][k];
+                        tdv += c[j][k] * db[1][k];
+                        tdd += c[j][k] * ddb[1][k];
+                    }
+                    q[j][0] = mul_rn<T>(t, ddb0r[a]);
+                    q[j][1] = mul_rn<T>(tdv, db0r[a]);
+                    q[j][2] = mul_rn<T>(tdd, b0r[a]);
+                }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) part[h][m] = add_rn<T>(q[0][m], q[1][m]);
+                asm volatile("" : "+v"(part[h][0]), "+v"(part[h][1]), "+v"(part[h][2]));
+            }
+            T suu, suv, svv;
+            if constexpr (O == 2) { suu = part[0][0]; suv = part[0][1]; svv = part[0][2]; }
+            else {
+                suu = add_rn<T>(part[0][0], part[1][0]);
+                suv = add_rn<T>(part[0][1], part[1][1]);
+                svv = add_rn<T>(part[0][2], part[1][2]);
+            }
+            L += suu * nrm[dep];
+            M += suv * nrm[dep];
+            Nn += svv * nrm[dep];
+#pragma unroll
+            for (int a = 0; a < O; ++a) ra[a] += dstride;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        rr_store(out, n * (unsigned)sizeof(T), (L * Nn - M * M) / (E * G - F * F));
+    }
+}
+
 }  // namespace bsk

@@ -830,3 +830,25 @@ def test_tessellate_full_teapot(golden_tables):
     for d in (du, dv):
         cosang = np.abs((d * n).sum(axis=1)) / np.maximum(np.sqrt((d ** 2).sum(axis=1)), 1e-12)
         assert np.nanmax(np.where(inner, cosang, 0.0)) <= 0.05
+
+
+def test_fused_curvature_orders_and_sizes():
+    """curv_rowrot (fused Gaussian curvature on the LDS image) for both template orders against the
+    oracle, on odd batch sizes; the piecewise bilinear case has S_uu = S_vv = 0."""
+    rng = np.random.default_rng(31)
+    for order, ncoef in (((2, 2), (9, 7)), ((4, 4), (12, 10))):
+        knots = [cases.nonuniform_knots(rng, o, c, np.float64, 0.0, 1.0) for o, c in zip(order, ncoef)]
+        coefs = rng.standard_normal((3, *ncoef))
+        t = DeviceSpline(order, ncoef, knots, coefs)
+        for n in (1, 65, 5003):
+            pts = [rng.random(n), rng.random(n)]
+            orc, bad = oracle.c_curvature(order, ncoef, knots, coefs, pts)
+            got = t.curvature(pts)
+            ok = np.isfinite(orc)
+            assert ok.mean() > 0.9 and np.array_equal(ok, np.isfinite(got))
+            assert np.abs(got[ok] - orc[ok]).max() <= 1e-9 * max(1.0, np.abs(orc[ok]).max()), (order, n)
+        bad = [rng.random(100), rng.random(100)]
+        bad[1][42] = 1.5
+        with pytest.raises(bspy_amd.DomainError) as e:
+            t.curvature(bad)
+        assert e.value.index == 42
