@@ -1,102 +1,10 @@
 // C ABI of libbspy_amd.so (see include/bspy_amd.h).  Host side: table construction,
 // kernel selection and launch, host<->device staging for BSK_HOST buffers.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <tuple>
-#include <vector>
-
 #include "bsk_kernels.hpp"
 #include "bsk_tile.hpp"
 #include "bsk_stream.hpp"
 #include "bsk_rowrot.hpp"
-#include "bsk_gather.hpp"
-#include "bsk_binned.hpp"
-
-using namespace bsk;
-
-// ------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static bsk_status fail(bsk_status st, const std::string &msg)
-{
-    g_err = msg;
-    return st;
-}
-
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
-    } while (0)
-
-// ------------------------------------------------------------------------------------
-// handle
-// ------------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct bsk_spline_s {
-    bsk_dtype dtype;
-    int device;
-    int nInd, nDep;
-    int order[MAXI], ncoef[MAXI];
-    bool same_order;         // every variable has the same order
-    size_t esize;
-    Desc<float> d32;
-    Desc<double> d64;
-    TileDesc<float> t32;
-    TileDesc<double> t64;
-    void *tab = nullptr;     // device axis table
-    void *coef = nullptr;    // device coefficients
-    void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
-    unsigned *lut = nullptr; // device span-search bucket tables
-    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot, 7 no cell-order evaluation, 6 cell order without LDS row bundles
-    unsigned long long *bad = nullptr;  // device out-of-domain record
-    int num_cu = 256;
-    size_t lds_max = 160 * 1024;
-    DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
-    DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
-    std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
-    void *pin = nullptr;                // pinned, device-mapped host buffer of the small-call path (run_small)
-    size_t pin_cap = 0;
-};
-
-template <typename T>
-static Desc<T> &desc_of(bsk_spline s);
-template <>
-Desc<float> &desc_of<float>(bsk_spline s) { return s->d32; }
-template <>
-Desc<double> &desc_of<double>(bsk_spline s) { return s->d64; }
-template <typename T>
-static TileDesc<T> &tile_of(bsk_spline s);
-template <>
-TileDesc<float> &tile_of<float>(bsk_spline s) { return s->t32; }
-template <>
-TileDesc<double> &tile_of<double>(bsk_spline s) { return s->t64; }
+#include "bsk_host.hpp"
 
 static int ceil_log2(int x)
 {
@@ -390,23 +298,6 @@ static Plan make_plan(bsk_spline s, long long n)
     return p;
 }
 
-// Raise a kernel's dynamic-LDS limit above 64 KiB.  hipFuncSetAttribute is a driver call
-// (tens of microseconds): it is issued once per kernel, device and size, not per launch.
-template <typename K>
-static hipError_t allow_lds(K kernel, size_t bytes)
-{
-    if (bytes <= 64 * 1024) return hipSuccess;
-    static thread_local std::vector<std::tuple<const void *, int, size_t>> done;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const void *fn = reinterpret_cast<const void *>(kernel);
-    for (const auto &e : done)
-        if (std::get<0>(e) == fn && std::get<1>(e) == dev && std::get<2>(e) >= bytes) return hipSuccess;
-    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (err == hipSuccess) done.emplace_back(fn, dev, bytes);
-    return err;
-}
-
 template <typename T, int NIND, int O>
 static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T> &prm, long long n, T *out,
                                     long long ostride, const Wrt &w, hipStream_t st)
@@ -634,153 +525,17 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
     return BSK_OK;
 }
 
-template <typename T, int NIND, int O>
-static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
-                                     const Wrt &w, hipStream_t st)
-{
-    const Desc<T> &d = desc_of<T>(s);
-    const size_t lds = sizeof(T) * (size_t)d.tab_len;
-    if (lds > s->lds_max / 2) return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
-    const int block = 256;
-    const long long blocks = (n + block - 1) / block;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
-    const T *tab = static_cast<const T *>(s->tab);
-    const T *aos = static_cast<const T *>(s->coef_aos);
-#define GATHER_ND(ND)                                                                                             \
-    case ND:                                                                                                      \
-        if (s->same_order) {                                                                                      \
-            HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, false>, lds));                                           \
-            hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, false>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, \
-                               n, out, ostride, w, s->bad);                                                       \
-        } else {                                                                                                  \
-            HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, true>, lds));                                            \
-            hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, true>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, \
-                               n, out, ostride, w, s->bad);                                                       \
-        }                                                                                                         \
-        break;
-    switch (s->nDep) {
-        GATHER_ND(1) GATHER_ND(2) GATHER_ND(3) GATHER_ND(4)
-        default: return fail(BSK_ERR_INVALID, "internal: eval_gather needs nDep <= 4");
-    }
-#undef GATHER_ND
-    HIPCHK(hipGetLastError());
-    return BSK_OK;
-}
-
-// Cell-order evaluation of large batches on L2-resident tables (bsk_binned.hpp).  Returns
-// BSK_ERR_UNSUPPORTED when it does not apply (the caller then gathers in batch order).
-constexpr long long BIN_MIN_POINTS = 1 << 18;
-#ifndef BIN_CHUNK_POINTS
-#define BIN_CHUNK_POINTS 8192
-#endif
-
-template <typename T, int NIND, int O>
-static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
-                                     const Wrt &w, hipStream_t st)
-{
-    if constexpr (NIND < 2) {
-        return BSK_ERR_UNSUPPORTED;
-    } else {
-        if (n < BIN_MIN_POINTS || n > 0xffffffffll || !s->coef_aos || s->variant == 7 || s->nDep > 4) return BSK_ERR_UNSUPPORTED;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            return BSK_ERR_UNSUPPORTED;                       // the workspace may have to be (re)allocated
-        }
-        const Desc<T> &d = desc_of<T>(s);
-        BinPlan bp;
-        const int s0 = s->ncoef[0] - s->order[0] + 1, s1 = s->ncoef[1] - s->order[1] + 1;   // spans (O = largest order)
-        bp.sh0 = bp.sh1 = 0;
-        auto cells_of = [&](int sh0, int sh1) { return (((s0 - 1) >> sh0) + 1) * (((s1 - 1) >> sh1) + 1); };
-        while (cells_of(bp.sh0, bp.sh1) > BIN_MAX_CELLS) {
-            if ((s0 >> bp.sh0) >= (s1 >> bp.sh1)) ++bp.sh0; else ++bp.sh1;
-        }
-        bp.n1 = ((s1 - 1) >> bp.sh1) + 1;
-        bp.cells = cells_of(bp.sh0, bp.sh1);
-        bp.chunks = (int)std::max<long long>(1, std::min<long long>(BIN_MAX_CHUNKS, (n + BIN_CHUNK_POINTS - 1) / BIN_CHUNK_POINTS));
-        bp.chunk = (n + bp.chunks - 1) / bp.chunks;
-        const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
-        const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)bp.cells;
-        if (lds_count > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
-
-        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t o_cell = 0, o_slot = o_cell + up(2 * (size_t)n), o_rec = o_slot + up(4 * (size_t)n);
-        const size_t o_tmp = o_rec + up(sizeof(BinRec<T, NIND>) * (size_t)n);
-        size_t o_M = 0, o_tot = 0, o_start = 0, total = 0;
-        auto layout = [&](size_t out_bytes) {
-            o_M = o_tmp + up(out_bytes * (size_t)n);
-            o_tot = o_M + up(4 * (size_t)bp.cells * bp.chunks);
-            o_start = o_tot + up(4 * (size_t)bp.cells);
-            total = o_start + up(4 * (size_t)bp.cells);
-        };
-        const T *tab = static_cast<const T *>(s->tab);
-        const T *aos = static_cast<const T *>(s->coef_aos);
-        const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
-        // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
-        const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
-        const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
-        const bool bundle_ok = s->variant != 6 && tab_b + bundle_b <= s->lds_max / 2;
-#define BINNED_ND(ND)                                                                                                    \
-    case ND: {                                                                                                           \
-        layout(sizeof(BinOut<T, ND>));                                                                                   \
-        HIPCHK(s->bin_ws.reserve(total));                                                                                \
-        char *ws = static_cast<char *>(s->bin_ws.p);                                                                     \
-        unsigned short *cell = reinterpret_cast<unsigned short *>(ws + o_cell);                                          \
-        unsigned *slot = reinterpret_cast<unsigned *>(ws + o_slot);                                                      \
-        BinRec<T, NIND> *rec = reinterpret_cast<BinRec<T, NIND> *>(ws + o_rec);                                          \
-        BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
-        unsigned *M = reinterpret_cast<unsigned *>(ws + o_M);                                                            \
-        unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
-        unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
-        HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
-        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(BIN_BLOCK), lds_count, st, d, bp, tab, prm, n, \
-                           cell, M, s->bad);                                                                             \
-        hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
-        hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
-        hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(BIN_BLOCK), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, start, rec, slot);                                                   \
-        if (bundle_ok && s->same_order) {                                                                                \
-            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, false>, tab_b + bundle_b));                                 \
-            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, false>), dim3(egrid), dim3(256), tab_b + bundle_b, st,   \
-                               d, bp, tab, aos, start, rec, n, tmp, w);                                                  \
-        } else if (bundle_ok) {                                                                                          \
-            HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, true>, tab_b + bundle_b));                                  \
-            hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, true>), dim3(egrid), dim3(256), tab_b + bundle_b, st,    \
-                               d, bp, tab, aos, start, rec, n, tmp, w);                                                  \
-        } else if (s->same_order) {                                                                                      \
-            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND, false>, tab_b));                                                \
-            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND, false>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos,     \
-                               rec, n, tmp, w);                                                                          \
-        } else {                                                                                                         \
-            HIPCHK(allow_lds(eval_binned<T, NIND, O, ND, true>, tab_b));                                                 \
-            hipLaunchKernelGGL((eval_binned<T, NIND, O, ND, true>), dim3(egrid), dim3(256), tab_b, st, d, tab, aos,      \
-                               rec, n, tmp, w);                                                                          \
-        }                                                                                                                \
-        hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(egrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
-    } break;
-        switch (s->nDep) {
-            BINNED_ND(1) BINNED_ND(2) BINNED_ND(3) BINNED_ND(4)
-            default: return BSK_ERR_UNSUPPORTED;
-        }
-#undef BINNED_ND
-        HIPCHK(hipGetLastError());
-        return BSK_OK;
-    }
-}
-
-template <typename T, int NIND, int O>
-static bsk_status gather_or_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
-                                   const Wrt &w, hipStream_t st)
-{
-    const bsk_status r = launch_eval_binned<T, NIND, O>(s, prm, n, out, ostride, w, st);
-    if (r != BSK_ERR_UNSUPPORTED) return r;
-    return launch_eval_gather<T, NIND, O>(s, prm, n, out, ostride, w, st);
-}
-
 // Fast-path coverage: nInd 1..3, one common order 1..6.
 static bool has_fixed_path(bsk_spline s)
 {
     return s->same_order && s->nInd >= 1 && s->nInd <= 3 && s->order[0] >= 1 && s->order[0] <= 6;
+}
+
+// The LDS-staging kernels (eval_fixed / jac_fixed / eval_mixed) keep at least the axis tables in LDS.
+static bool axis_tables_fit_lds(bsk_spline s)
+{
+    const size_t tab_len = s->dtype == BSK_F32 ? (size_t)s->d32.tab_len : (size_t)s->d64.tab_len;
+    return s->esize * (tab_len + 2) + 1024 <= s->lds_max;
 }
 
 #define BSK_ORDER_SWITCH(NIND, CALL)                        \
@@ -849,13 +604,11 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         }
     }
     if (has_fixed_path(s) && s->coef_aos && s->variant != 1) {
-#define CALL_GATHER(NIND, O) gather_or_binned<T, NIND, O>(s, prm, n, out, ostride, w, st)
-        if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_GATHER) }
-        else if (s->nInd == 2) { BSK_ORDER_SWITCH(2, CALL_GATHER) }
-        else { BSK_ORDER_SWITCH(3, CALL_GATHER) }
-#undef CALL_GATHER
+        // table too large for LDS: control-point-major gather / cell-order pipeline (bsk_gather_tu.hip)
+        const bsk_status r = gather_or_binned_any<T>(s, false, prm, n, out, ostride, w, st);
+        if (r != BSK_ERR_UNSUPPORTED) return r;
     }
-    if (has_fixed_path(s)) {
+    if (has_fixed_path(s) && axis_tables_fit_lds(s)) {
         const Plan p = make_plan<T>(s, n);
 #define CALL_EVAL(NIND, O) launch_eval_fixed<T, NIND, O>(s, p, prm, n, out, ostride, w, st)
         if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_EVAL) }
@@ -864,22 +617,13 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
 #undef CALL_EVAL
     }
     // What is left: variables of different orders, or orders beyond the fixed-order kernels.
-    if (s->nInd >= 1 && s->nInd <= 5 && s->variant != 1) {
+    if (s->nInd >= 1 && s->nInd <= 5 && s->variant != 1 && axis_tables_fit_lds(s)) {
         int omax = 0;
         for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
         if (!s->same_order && omax >= 2 && omax <= 6 && s->coef_aos) {
             // table too large for LDS: control-point-major gather / cell-order pipeline at O = omax
-#define CALL_GATHER_M(NIND)                                                                       \
-    switch (omax) {                                                                               \
-        case 2: return gather_or_binned<T, NIND, 2>(s, prm, n, out, ostride, w, st);              \
-        case 3: return gather_or_binned<T, NIND, 3>(s, prm, n, out, ostride, w, st);              \
-        case 4: return gather_or_binned<T, NIND, 4>(s, prm, n, out, ostride, w, st);              \
-        case 5: return gather_or_binned<T, NIND, 5>(s, prm, n, out, ostride, w, st);              \
-        default: return gather_or_binned<T, NIND, 6>(s, prm, n, out, ostride, w, st);             \
-    }
-            if (s->nInd == 2) { CALL_GATHER_M(2) }
-            else if (s->nInd == 3) { CALL_GATHER_M(3) }
-#undef CALL_GATHER_M
+            const bsk_status r = gather_or_binned_any<T>(s, true, prm, n, out, ostride, w, st);
+            if (r != BSK_ERR_UNSUPPORTED) return r;
         }
         // eval_mixed: surfaces up to order 8, volumes up to 6, curves up to 12, four variables up to order 4, five up to 3
         const Plan p = make_plan<T>(s, n);
@@ -931,7 +675,7 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
 #undef CALL_JACS
         }
     }
-    if (has_fixed_path(s)) {
+    if (has_fixed_path(s) && axis_tables_fit_lds(s)) {
         const Plan p = make_plan<T>(s, n);
 #define CALL_JAC(NIND, O) launch_jac_fixed<T, NIND, O>(s, p, prm, n, out, st)
         if (s->nInd == 1) { BSK_ORDER_SWITCH(1, CALL_JAC) }

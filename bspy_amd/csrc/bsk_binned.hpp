@@ -15,8 +15,9 @@
 //   bin_topscan  one workgroup: exclusive scan of the cell totals
 //   bin_scatter  same chunks: slot = start[cell] + M[cell][chunk] + rank inside the chunk (LDS
 //                atomic); writes the record {u..} to rec[slot] and slot[n]
-//   eval_binned  eval_gather's arithmetic on the records in slot order, control point results
-//                to tmp[slot] (one 16/32-byte store per point)
+//   eval_binned_lds  eval_gather's arithmetic on the records in slot order with the cell's
+//                coefficient rows staged in LDS; control point results to tmp[slot] (one
+//                16/32-byte store per point)
 //   bin_unpermute out[dep][n] = tmp[slot[n]][dep]: gathered 16/32-byte reads, coalesced SoA stores
 //
 // No global atomics (64 lanes adding to 64 different addresses run at 0.08 TB/s on MI355X); a
@@ -223,57 +224,13 @@ __device__ __forceinline__ void window_contract(CP w0, int s0, int s1, const int
     }
 }
 
-// eval_gather's arithmetic on the records (slot order); results control-point-major in tmp[slot]
-template <typename T, int NIND, int O, int ND, bool MIXED>
-__global__ __launch_bounds__(256) void eval_binned(const Desc<T> d, const T *__restrict__ gtab, const T *__restrict__ aos,
-                                                   const BinRec<T, NIND> *__restrict__ rec, const long long N,
-                                                   BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T *stab = reinterpret_cast<T *>(smem);
-    for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
-    __syncthreads();
-    int cs[NIND];
-    cs[NIND - 1] = 1;
-#pragma unroll
-    for (int iv = NIND - 2; iv >= 0; --iv) cs[iv] = cs[iv + 1] * d.ncoef[iv + 1];
-    int pad[NIND];
-#pragma unroll
-    for (int iv = 0; iv < NIND; ++iv) pad[iv] = O - d.order[iv];
-
-    // consecutive slots to consecutive lanes, a workgroup walks a contiguous range (neighbouring
-    // waves share cells -> the row bundle stays in this CU's L1)
-    const long long per = (N + gridDim.x - 1) / gridDim.x;
-    const long long lo = (long long)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
-    for (long long p = lo + threadIdx.x; p < hi; p += blockDim.x) {
-        const BinRec<T, NIND> rc = rec[p];
-        T b[NIND][O];
-        int base = 0;
-#pragma unroll
-        for (int iv = 0; iv < NIND; ++iv) {
-            const T u = rc.v[iv];
-            const T *tab = stab + d.off[iv];
-            const int ix = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
-            if constexpr (MIXED) basis_bounded<T, O>(tab, d.nk[iv], d.order[iv], ix, u, wrt.w[iv], b[iv]);
-            else basis_fixed<T, O>(tab, d.nk[iv], ix, u, wrt.w[iv], b[iv]);
-            base += (ix - O) * cs[iv];
-        }
-        const T *__restrict__ w0 = aos + (long long)base * ND;
-        T r[ND];
-        window_contract<T, NIND, O, ND, MIXED>(w0, cs[0], NIND == 3 ? cs[1] : 1, pad, b, r);
-        BinOut<T, ND> o;
-#pragma unroll
-        for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? r[k < ND ? k : 0] : T(0);
-        tmp[p] = o;
-    }
-}
-
-// eval_binned with the coefficient rows of the current cell staged in LDS.
+// eval_binned_lds: eval_gather's arithmetic on the records in slot order, with the coefficient rows
+// of the current cell staged in LDS; results control-point-major in tmp[slot].
 // All points of a cell read the same bundle of rows: R0 (x R1 for three variables) rows of the
 // first (two) variable(s), each a full line of the last variable (cfg5: 25 rows x 640 B = 16 KB).
-// eval_binned walks its windows through the vector L1 - 2 KB per point at 64 B/clk/CU, which is
-// what bounds it; the bundle is read from L2 once per cell and workgroup instead and the windows
-// come from LDS (256 B/clk/CU).  A workgroup owns a contiguous slot range and goes through the
+// Walking the windows through the vector L1 costs 2 KB per point at 64 B/clk/CU (measured: 843 us
+// per 10 M cfg5 points in cell order); the bundle is read from L2 once per cell and workgroup
+// instead and the windows come from LDS (256 B/clk/CU; 414 us).  A workgroup owns a contiguous slot range and goes through the
 // cells that overlap it.  LDS: [axis tables][bundle]
 template <typename T, int NIND, int O, int ND, bool MIXED>
 __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,

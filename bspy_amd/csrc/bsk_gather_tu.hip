@@ -1,0 +1,158 @@
+// Large-table evaluation paths of libbspy_amd.so in their own translation unit (two thirds of the
+// device code; compiled in parallel with bsk_api.hip): eval_gather (control-point-major gather
+// from L2) and the cell-order pipeline (bsk_binned.hpp).  Entry: gather_or_binned_any<T>.
+#include "bsk_host.hpp"
+#include "bsk_tile.hpp"
+#include "bsk_gather.hpp"
+#include "bsk_binned.hpp"
+
+template <typename T, int NIND, int O, bool MIXED>
+static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                     const Wrt &w, hipStream_t st)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const size_t lds = sizeof(T) * (size_t)d.tab_len;
+    if (lds > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;        // axis tables too large for LDS: the caller falls back
+    const int block = 256;
+    const long long blocks = (n + block - 1) / block;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *aos = static_cast<const T *>(s->coef_aos);
+#define GATHER_ND(ND)                                                                                             \
+    case ND:                                                                                                      \
+        HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, MIXED>, lds));                                               \
+        hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, MIXED>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, n,  \
+                           out, ostride, w, s->bad);                                                              \
+        break;
+    switch (s->nDep) {
+        GATHER_ND(1) GATHER_ND(2) GATHER_ND(3) GATHER_ND(4)
+        default: return fail(BSK_ERR_INVALID, "internal: eval_gather needs nDep <= 4");
+    }
+#undef GATHER_ND
+    HIPCHK(hipGetLastError());
+    return BSK_OK;
+}
+
+// Cell-order evaluation of large batches on L2-resident tables (bsk_binned.hpp).  Returns
+// BSK_ERR_UNSUPPORTED when it does not apply (the caller then gathers in batch order).
+constexpr long long BIN_MIN_POINTS = 1 << 18;
+#ifndef BIN_CHUNK_POINTS
+#define BIN_CHUNK_POINTS 8192
+#endif
+
+template <typename T, int NIND, int O, bool MIXED>
+static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                     const Wrt &w, hipStream_t st)
+{
+    if constexpr (NIND < 2) {
+        return BSK_ERR_UNSUPPORTED;
+    } else {
+        if (n < BIN_MIN_POINTS || n > 0xffffffffll || !s->coef_aos || s->variant == 7 || s->nDep > 4) return BSK_ERR_UNSUPPORTED;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return BSK_ERR_UNSUPPORTED;                       // the workspace may have to be (re)allocated
+        }
+        const Desc<T> &d = desc_of<T>(s);
+        BinPlan bp;
+        const int s0 = s->ncoef[0] - s->order[0] + 1, s1 = s->ncoef[1] - s->order[1] + 1;   // spans (O = largest order)
+        bp.sh0 = bp.sh1 = 0;
+        auto cells_of = [&](int sh0, int sh1) { return (((s0 - 1) >> sh0) + 1) * (((s1 - 1) >> sh1) + 1); };
+        while (cells_of(bp.sh0, bp.sh1) > BIN_MAX_CELLS) {
+            if ((s0 >> bp.sh0) >= (s1 >> bp.sh1)) ++bp.sh0; else ++bp.sh1;
+        }
+        bp.n1 = ((s1 - 1) >> bp.sh1) + 1;
+        bp.cells = cells_of(bp.sh0, bp.sh1);
+        bp.chunks = (int)std::max<long long>(1, std::min<long long>(BIN_MAX_CHUNKS, (n + BIN_CHUNK_POINTS - 1) / BIN_CHUNK_POINTS));
+        bp.chunk = (n + bp.chunks - 1) / bp.chunks;
+        const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
+        const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)bp.cells;
+        if (lds_count > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
+
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_cell = 0, o_slot = o_cell + up(2 * (size_t)n), o_rec = o_slot + up(4 * (size_t)n);
+        const size_t o_tmp = o_rec + up(sizeof(BinRec<T, NIND>) * (size_t)n);
+        size_t o_M = 0, o_tot = 0, o_start = 0, total = 0;
+        auto layout = [&](size_t out_bytes) {
+            o_M = o_tmp + up(out_bytes * (size_t)n);
+            o_tot = o_M + up(4 * (size_t)bp.cells * bp.chunks);
+            o_start = o_tot + up(4 * (size_t)bp.cells);
+            total = o_start + up(4 * (size_t)bp.cells);
+        };
+        const T *tab = static_cast<const T *>(s->tab);
+        const T *aos = static_cast<const T *>(s->coef_aos);
+        const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
+        // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
+        const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
+        const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
+        if (tab_b + bundle_b > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;   // rows of a cell must fit LDS twice per CU
+#define BINNED_ND(ND)                                                                                                    \
+    case ND: {                                                                                                           \
+        layout(sizeof(BinOut<T, ND>));                                                                                   \
+        HIPCHK(s->bin_ws.reserve(total));                                                                                \
+        char *ws = static_cast<char *>(s->bin_ws.p);                                                                     \
+        unsigned short *cell = reinterpret_cast<unsigned short *>(ws + o_cell);                                          \
+        unsigned *slot = reinterpret_cast<unsigned *>(ws + o_slot);                                                      \
+        BinRec<T, NIND> *rec = reinterpret_cast<BinRec<T, NIND> *>(ws + o_rec);                                          \
+        BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
+        unsigned *M = reinterpret_cast<unsigned *>(ws + o_M);                                                            \
+        unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
+        unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
+        HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
+        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(BIN_BLOCK), lds_count, st, d, bp, tab, prm, n, \
+                           cell, M, s->bad);                                                                             \
+        hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
+        hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
+        hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(BIN_BLOCK), sizeof(unsigned) * (size_t)bp.cells, \
+                           st, bp, prm, n, cell, M, start, rec, slot);                                                   \
+        HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, MIXED>, tab_b + bundle_b));                                     \
+        hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, MIXED>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d,    \
+                           bp, tab, aos, start, rec, n, tmp, w);                                                         \
+        hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(egrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
+    } break;
+        switch (s->nDep) {
+            BINNED_ND(1) BINNED_ND(2) BINNED_ND(3) BINNED_ND(4)
+            default: return BSK_ERR_UNSUPPORTED;
+        }
+#undef BINNED_ND
+        HIPCHK(hipGetLastError());
+        return BSK_OK;
+    }
+}
+
+// MIXED: variables of different orders (O = the largest); chosen by the call site so that every
+// (NIND, O) instantiates one form only
+template <typename T, int NIND, int O, bool MIXED>
+static bsk_status gather_or_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
+                                   const Wrt &w, hipStream_t st)
+{
+    const bsk_status r = launch_eval_binned<T, NIND, O, MIXED>(s, prm, n, out, ostride, w, st);
+    if (r != BSK_ERR_UNSUPPORTED) return r;
+    return launch_eval_gather<T, NIND, O, MIXED>(s, prm, n, out, ostride, w, st);
+}
+
+
+template <typename T>
+bsk_status gather_or_binned_any(bsk_spline s, bool mixed, const Params<T> &prm, long long n, T *out, long long ostride,
+                                const Wrt &w, hipStream_t st)
+{
+    int omax = 0;
+    for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
+    if (s->nInd < 1 || s->nInd > 3 || omax < 1 || omax > 6 || !s->coef_aos) return BSK_ERR_UNSUPPORTED;
+#define GB_CASE(NIND, O, MIXED) case O: return gather_or_binned<T, NIND, O, MIXED>(s, prm, n, out, ostride, w, st);
+    if (!mixed) {
+        if (s->nInd == 1) switch (omax) { GB_CASE(1, 1, false) GB_CASE(1, 2, false) GB_CASE(1, 3, false) GB_CASE(1, 4, false) GB_CASE(1, 5, false) GB_CASE(1, 6, false) default: break; }
+        else if (s->nInd == 2) switch (omax) { GB_CASE(2, 1, false) GB_CASE(2, 2, false) GB_CASE(2, 3, false) GB_CASE(2, 4, false) GB_CASE(2, 5, false) GB_CASE(2, 6, false) default: break; }
+        else switch (omax) { GB_CASE(3, 1, false) GB_CASE(3, 2, false) GB_CASE(3, 3, false) GB_CASE(3, 4, false) GB_CASE(3, 5, false) GB_CASE(3, 6, false) default: break; }
+    } else {
+        if (s->nInd == 2) switch (omax) { GB_CASE(2, 2, true) GB_CASE(2, 3, true) GB_CASE(2, 4, true) GB_CASE(2, 5, true) GB_CASE(2, 6, true) default: break; }
+        else if (s->nInd == 3) switch (omax) { GB_CASE(3, 2, true) GB_CASE(3, 3, true) GB_CASE(3, 4, true) GB_CASE(3, 5, true) GB_CASE(3, 6, true) default: break; }
+    }
+#undef GB_CASE
+    return BSK_ERR_UNSUPPORTED;
+}
+
+template bsk_status gather_or_binned_any<float>(bsk_spline, bool, const Params<float> &, long long, float *, long long,
+                                                const Wrt &, hipStream_t);
+template bsk_status gather_or_binned_any<double>(bsk_spline, bool, const Params<double> &, long long, double *, long long,
+                                                 const Wrt &, hipStream_t);

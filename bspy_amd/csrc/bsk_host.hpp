@@ -1,0 +1,124 @@
+// Host-side declarations shared by the translation units of libbspy_amd.so: error reporting, the
+// spline handle, and small launch helpers.  (The kernels of the large-table paths - control-point
+// major gather and the cell-order pipeline - are two thirds of the device code; they are compiled
+// in their own translation unit, bsk_gather_tu.hip, in parallel with bsk_api.hip.)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "bsk_common.hpp"
+#include "bsk_tile.hpp"      // TileDesc
+
+using namespace bsk;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+inline thread_local std::string g_err;
+
+inline bsk_status fail(bsk_status st, const std::string &msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(BSK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct bsk_spline_s {
+    bsk_dtype dtype;
+    int device;
+    int nInd, nDep;
+    int order[MAXI], ncoef[MAXI];
+    bool same_order;         // every variable has the same order
+    size_t esize;
+    Desc<float> d32;
+    Desc<double> d64;
+    TileDesc<float> t32;
+    TileDesc<double> t64;
+    void *tab = nullptr;     // device axis table
+    void *coef = nullptr;    // device coefficients
+    void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
+    unsigned *lut = nullptr; // device span-search bucket tables
+    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot, 7 no cell-order evaluation, 6 cell order without LDS row bundles
+    unsigned long long *bad = nullptr;  // device out-of-domain record
+    int num_cu = 256;
+    size_t lds_max = 160 * 1024;
+    DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
+    DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
+    std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
+    void *pin = nullptr;                // pinned, device-mapped host buffer of the small-call path (run_small)
+    size_t pin_cap = 0;
+};
+
+template <typename T>
+Desc<T> &desc_of(bsk_spline s);
+template <>
+inline Desc<float> &desc_of<float>(bsk_spline s) { return s->d32; }
+template <>
+inline Desc<double> &desc_of<double>(bsk_spline s) { return s->d64; }
+template <typename T>
+TileDesc<T> &tile_of(bsk_spline s);
+template <>
+inline TileDesc<float> &tile_of<float>(bsk_spline s) { return s->t32; }
+template <>
+inline TileDesc<double> &tile_of<double>(bsk_spline s) { return s->t64; }
+
+
+// Raise a kernel's dynamic-LDS limit above 64 KiB.  hipFuncSetAttribute is a driver call
+// (tens of microseconds): it is issued once per kernel, device and size, not per launch.
+template <typename K>
+inline hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static thread_local std::vector<std::tuple<const void *, int, size_t>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    for (const auto &e : done)
+        if (std::get<0>(e) == fn && std::get<1>(e) == dev && std::get<2>(e) >= bytes) return hipSuccess;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err == hipSuccess) done.emplace_back(fn, dev, bytes);
+    return err;
+}
+
+
+// Large-table evaluation (bsk_gather_tu.hip): control-point-major gather, or the cell-order pipeline
+// for batches of >= 2^18 points.  `mixed`: variables of different orders (kernels run at the largest).
+// Returns BSK_ERR_UNSUPPORTED when the shape is not covered (the caller falls back).
+template <typename T>
+bsk_status gather_or_binned_any(bsk_spline s, bool mixed, const Params<T> &prm, long long n, T *out, long long ostride,
+                                const Wrt &w, hipStream_t st);

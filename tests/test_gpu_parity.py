@@ -484,13 +484,10 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
     t = DeviceSpline(order, ncoef, knots, coefs, dt)
     monkeypatch.setenv("BSK_VARIANT", "7")
     plain = DeviceSpline(order, ncoef, knots, coefs, dt)
-    monkeypatch.setenv("BSK_VARIANT", "6")                   # cell order, windows through L1 instead of LDS bundles
-    nolds = DeviceSpline(order, ncoef, knots, coefs, dt)
     sample = rng.choice(n, 20_000, replace=False)
     for w in ([0] * nind, [1] + [0] * (nind - 1), [0] * (nind - 1) + [2]):
         out = t.evaluate(pts, w)
         assert np.array_equal(out, plain.evaluate(pts, w)), (shape, w)
-        assert np.array_equal(out, nolds.evaluate(pts, w)), (shape, w)
         orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, [p[sample] for p in pts])
         assert bad == -1
         assert np.abs(out[:, sample] - orc).max() <= tol * _scale(orc), (shape, w)
