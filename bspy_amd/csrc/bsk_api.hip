@@ -1307,20 +1307,20 @@ static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *co
         const int gx = (int)std::max<long long>(1, std::min<long long>(g.n[0], std::max<long long>(1, (long long)s->num_cu * 8 / np)));
         T *pp = dpos + (size_t)p0 * 3 * (size_t)total;
         T *pn = dnrm ? dnrm + (size_t)p0 * 3 * (size_t)total : nullptr;
+#define TESS_LAUNCH(O, NRM, MIX)                                                                                       \
+    hipLaunchKernelGGL((tess_rows<T, O, NRM, MIX>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows,             \
+                       NRM ? drows : rows, outside, pp, pn, s->bad, vec_ok, normalize, negate)
 #define TESS(O)                                                                                                        \
     case O:                                                                                                            \
-        if (normals)                                                                                                   \
-            hipLaunchKernelGGL((tess_rows<T, O, true>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows, drows,  \
-                               outside, pp, pn, s->bad, vec_ok, normalize, negate);                                    \
-        else                                                                                                           \
-            hipLaunchKernelGGL((tess_rows<T, O, false>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows, rows,  \
-                               outside, pp, pn, s->bad, vec_ok, normalize, negate);                                    \
+        if (s->same_order) { if (normals) TESS_LAUNCH(O, true, false); else TESS_LAUNCH(O, false, false); }            \
+        else { if (normals) TESS_LAUNCH(O, true, true); else TESS_LAUNCH(O, false, true); }                            \
         break;
-        switch (s->order[0]) {
+        switch (std::max(s->order[0], s->order[1])) {
             TESS(1) TESS(2) TESS(3) TESS(4) TESS(5) TESS(6)
             default: return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: orders 1..6");
         }
 #undef TESS
+#undef TESS_LAUNCH
     }
     HIPCHK(hipGetLastError());
     if (mem == BSK_HOST) {
@@ -1341,8 +1341,8 @@ extern "C" bsk_status bsk_tessellate(const bsk_spline *splines, int count, const
     bsk_spline s = splines[0];
     if (!s) return fail(BSK_ERR_INVALID, "NULL handle");
     if (s->nInd != 2 || s->nDep != 3) return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: surfaces in 3-D (nInd 2, nDep 3)");
-    if (!s->same_order || s->order[0] > 6 || sizeof(double) * 6 * (size_t)s->ncoef[1] > 60 * 1024)
-        return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: one common order <= 6, nCoef[1] <= 1280");
+    if (std::max(s->order[0], s->order[1]) > 6 || sizeof(double) * 6 * (size_t)s->ncoef[1] > 60 * 1024)
+        return fail(BSK_ERR_UNSUPPORTED, "bsk_tessellate: orders <= 6, nCoef[1] <= 1280");
     for (int i = 1; i < count; ++i) {
         bsk_spline t = splines[i];
         if (!t) return fail(BSK_ERR_INVALID, "NULL handle");

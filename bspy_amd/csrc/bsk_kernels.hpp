@@ -544,7 +544,8 @@ __device__ __forceinline__ void tess_normal(const T (&su)[3], const T (&sv)[3], 
     n[0] = nx; n[1] = ny; n[2] = nz;
 }
 
-template <typename T, int O, bool NORMALS>
+// MIXED: the two variables have different orders o0, o1 <= O (as grid_rows).
+template <typename T, int O, bool NORMALS, bool MIXED>
 __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoefs<T> pc, const GridDims g,
                                                  const int *__restrict__ ixs, const T *__restrict__ rows,
                                                  const T *__restrict__ drows, const unsigned char *__restrict__ outside,
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
 {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     const int nc1 = d.ncoef[1], s0 = d.cstride[1];
+    const int o0 = MIXED ? d.order[0] : O, o1 = MIXED ? d.order[1] : O;
     T *rowc = reinterpret_cast<T *>(smem_g);                  // [3][nCoef1]
     T *drowc = rowc + 3 * nc1;                                // [3][nCoef1]  (NORMALS)
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -567,19 +569,22 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
         T b0[O], db0[O];
 #pragma unroll
         for (int a = 0; a < O; ++a) {
-            b0[a] = rows[g.roff[0] + i0 * O + a];
-            db0[a] = NORMALS ? drows[g.roff[0] + i0 * O + a] : T(0);
+            const bool on = !MIXED || a < o0;
+            b0[a] = on ? rows[g.roff[0] + i0 * o0 + a] : T(0);
+            db0[a] = (NORMALS && on) ? drows[g.roff[0] + i0 * o0 + a] : T(0);
         }
         __syncthreads();                                       // the previous row's readers are done
         for (int e = threadIdx.x; e < 3 * nc1; e += blockDim.x) {
             const int dep = e / nc1, c = e - dep * nc1;
-            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - O) * s0 + c;
+            const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - o0) * s0 + c;
             T acc = T(0), dacc = T(0);
 #pragma unroll
             for (int a = 0; a < O; ++a) {
-                const T cv = col[a * s0];
-                acc += b0[a] * cv;
-                dacc += db0[a] * cv;
+                if (!MIXED || a < o0) {
+                    const T cv = col[a * s0];
+                    acc += b0[a] * cv;
+                    dacc += db0[a] * cv;
+                }
             }
             rowc[e] = acc;
             if constexpr (NORMALS) drowc[e] = dacc;
@@ -592,12 +597,13 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 if (v < nv) {
-                    const int ix1 = ixs[g.goff[1] + c0 + v] - O;
+                    const int ix1 = ixs[g.goff[1] + c0 + v] - o1;
                     T b1[O], db1[O];
 #pragma unroll
                     for (int k = 0; k < O; ++k) {
-                        b1[k] = rows[g.roff[1] + (c0 + v) * O + k];
-                        db1[k] = NORMALS ? drows[g.roff[1] + (c0 + v) * O + k] : T(0);
+                        const bool on = !MIXED || k < o1;
+                        b1[k] = on ? rows[g.roff[1] + (c0 + v) * o1 + k] : T(0);
+                        db1[k] = (NORMALS && on) ? drows[g.roff[1] + (c0 + v) * o1 + k] : T(0);
                     }
                     if (blockIdx.y == 0 && (bad0 | (outside[g.goff[1] + c0 + v] != 0))) record_bad(bad, i0 * n1 + c0 + v);
                     T su[3], sv[3];
@@ -608,8 +614,10 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
                         T p = T(0), u_ = T(0), v_ = T(0);
 #pragma unroll
                         for (int k = 0; k < O; ++k) {
-                            p += rc[k] * b1[k];
-                            if constexpr (NORMALS) { u_ += drc[k] * b1[k]; v_ += rc[k] * db1[k]; }
+                            if (!MIXED || k < o1) {
+                                p += rc[k] * b1[k];
+                                if constexpr (NORMALS) { u_ += drc[k] * b1[k]; v_ += rc[k] * db1[k]; }
+                            }
                         }
                         P[dep][v] = p; su[dep] = u_; sv[dep] = v_;
                     }

@@ -210,6 +210,11 @@ def tess_cases():
     kv = clamped_uniform_knots(5, 8)
     patches = [((5, 5), (9, 8), [ku, kv], rng.standard_normal((3, 9, 8))) for _ in range(2)]
     out["o5_f64"] = (patches, np.linspace(0.0, 1.0, 6), np.linspace(0.0, 1.0, 8))
+    # three patches of order (2, 5) - a ruled-surface shape - and grid sizes that take the vector path
+    ku = nonuniform_knots(rng, 2, 6, np.float64, 0.0, 1.0)
+    kv = nonuniform_knots(rng, 5, 9, np.float64, 0.0, 3.0)
+    patches = [((2, 5), (6, 9), [ku, kv], rng.standard_normal((3, 6, 9))) for _ in range(3)]
+    out["o2x5_f64"] = (patches, np.linspace(0.0, 1.0, 7), np.linspace(0.0, 3.0, 10))
     return out
 
 
