@@ -683,6 +683,27 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
         else { BSK_ORDER_SWITCH(3, CALL_JAC) }
 #undef CALL_JAC
     }
+    // variables of different orders (or orders beyond jac_fixed) with LDS-resident tables: jac_mixed
+    if ((s->nInd == 2 || s->nInd == 3) && s->variant != 1 && axis_tables_fit_lds(s)) {
+        int omax = 0;
+        for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
+        const Plan p = make_plan<T>(s, n);
+        if (p.lds_coefs && omax >= 2 && omax <= (s->nInd == 2 ? 8 : 6)) {
+            const Desc<T> &d = desc_of<T>(s);
+            const T *tab = static_cast<const T *>(s->tab);
+            const T *coef = static_cast<const T *>(s->coef);
+#define JMIX(NIND, OM)                                                                                              \
+    case OM:                                                                                                        \
+        HIPCHK(allow_lds(jac_mixed<T, NIND, OM>, p.lds_bytes));                                                     \
+        hipLaunchKernelGGL((jac_mixed<T, NIND, OM>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef, prm, n, \
+                           out, s->bad);                                                                            \
+        HIPCHK(hipGetLastError());                                                                                  \
+        return BSK_OK;
+            if (s->nInd == 2) switch (omax) { JMIX(2, 2) JMIX(2, 3) JMIX(2, 4) JMIX(2, 5) JMIX(2, 6) JMIX(2, 7) JMIX(2, 8) default: break; }
+            else switch (omax) { JMIX(3, 2) JMIX(3, 3) JMIX(3, 4) JMIX(3, 5) JMIX(3, 6) default: break; }
+#undef JMIX
+        }
+    }
     // otherwise nInd unit-derivative passes, as the reference does (_spline_evaluation.py:205-213), each on the
     // best evaluation kernel for the shape (mixed orders: eval_mixed / gather; else eval_generic)
     for (int j = 0; j < s->nInd; ++j) {

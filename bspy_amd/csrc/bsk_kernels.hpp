@@ -133,6 +133,75 @@ __global__ __launch_bounds__(BLOCK_MAX) void eval_mixed(const Desc<T> d, const T
 }
 
 // ---------------------------------------------------------------------------------
+// fused jacobian for variables of different orders (and orders beyond jac_fixed): eval_mixed's
+// right-aligned windows with a value and a first-derivative basis per variable; partial j contracts
+// the window with db of variable j and b of the others.  Tables and coefficients in LDS.
+// out[(dep * NIND + j) * N + n]
+// ---------------------------------------------------------------------------------
+template <typename T, int NIND, int OMAX, int IV, int J>
+__device__ __forceinline__ T mixed_contract_d(const T *c, const int (&cstride)[MAXI + 1], const int (&pad)[NIND],
+                                              const T (&b)[NIND][OMAX], const T (&db)[NIND][OMAX])
+{
+    if constexpr (IV == NIND) {
+        return *c;
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int a = 0; a < OMAX; ++a)
+            if (a >= pad[IV])
+                acc += mixed_contract_d<T, NIND, OMAX, IV + 1, J>(c + a * cstride[IV + 1], cstride, pad, b, db) *
+                       (IV == J ? db[IV][a] : b[IV][a]);
+        return acc;
+    }
+}
+
+template <typename T, int NIND, int OMAX, int J>
+__device__ __forceinline__ void mixed_partials(const T *c, const int (&cstride)[MAXI + 1], const int (&pad)[NIND],
+                                               const T (&b)[NIND][OMAX], const T (&db)[NIND][OMAX], T *o, long long N)
+{
+    if constexpr (J < NIND) {
+        nt_store(&o[J * N], mixed_contract_d<T, NIND, OMAX, 0, J>(c, cstride, pad, b, db));
+        mixed_partials<T, NIND, OMAX, J + 1>(c, cstride, pad, b, db, o, N);
+    }
+}
+
+template <typename T, int NIND, int OMAX>
+__global__ __launch_bounds__(BLOCK_MAX) void jac_mixed(const Desc<T> d, const T *__restrict__ gtab,
+                                                       const T *__restrict__ gcoef, const Params<T> prm,
+                                                       const long long N, T *__restrict__ out,
+                                                       unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *stab = reinterpret_cast<T *>(smem);
+    T *scoef = stab + ((d.tab_len + 1) & ~1);
+    stage_tables(stab, scoef, gtab, d.tab_len, gcoef, d.coef_len, true);
+    int pad[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) pad[iv] = OMAX - d.order[iv];
+
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        T b[NIND][OMAX], db[NIND][OMAX];
+        int base = 0;
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            const T u = prm.p[iv][n];
+            outside |= (u < d.lo[iv]) | (u > d.hi[iv]);
+            const T *tab = stab + d.off[iv];
+            const int ix = find_span<T>(tab, d.order[iv], d.ncoef[iv], d.steps[iv], u);
+            basis_bounded<T, OMAX>(tab, d.nk[iv], d.order[iv], ix, u, 0, b[iv]);
+            basis_bounded<T, OMAX>(tab, d.nk[iv], d.order[iv], ix, u, 1, db[iv]);
+            base += (ix - OMAX) * d.cstride[iv + 1];
+        }
+        if (outside) record_bad(bad, n);
+        for (int dep = 0; dep < d.nDep; ++dep)
+            mixed_partials<T, NIND, OMAX, 0>(scoef + dep * d.cstride[0] + base, d.cstride, pad, b, db,
+                                             out + (long long)dep * NIND * N + n, N);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // fused jacobian: every first partial derivative from one span search and one
 // recursion per variable, coefficients read once.  out[(dep * NIND + j) * N + n]
 // ---------------------------------------------------------------------------------

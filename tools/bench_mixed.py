@@ -20,6 +20,11 @@ for name, order, ncoef, ndep in (("surface 3x4 20x20", (3, 4), (20, 20), 3), ("s
     o = torch.empty((ndep, n), dtype=torch.float64, device="cuda")
     s = timed(lambda: t.evaluate_device(p, out=o, check=False))
     print(f"{name:40s} {s*1e6:9.1f} us  {n/s/1e9:6.1f} G evals/s", flush=True)
+    if len(order) == 2:
+        jo = torch.empty((ndep, 2, n), dtype=torch.float64, device="cuda")
+        s = timed(lambda: t.jacobian_device(p, out=jo, check=False))
+        print(f"{'  jacobian':40s} {s*1e6:9.1f} us  {n/s/1e9:6.1f} G evals/s", flush=True)
+        del jo
 # grids: s(u[:, None], v[None, :]) on 2048 x 2048
 gg = torch.linspace(0, 1, 2048, dtype=torch.float64, device="cuda")
 for name, order, ncoef in (("grid 4x4 20x20", (4, 4), (20, 20)), ("grid 3x4 20x20", (3, 4), (20, 20)), ("grid 2x5 8x30", (2, 5), (8, 30))):
