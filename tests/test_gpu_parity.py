@@ -849,3 +849,50 @@ def test_fused_curvature_orders_and_sizes():
         with pytest.raises(bspy_amd.DomainError) as e:
             t.curvature(bad)
         assert e.value.index == 42
+
+
+def test_random_shapes_against_oracle():
+    """Differential sweep over the dispatcher: random nInd (1..5), orders (1..9, equal or different per
+    variable), nDep (1..6), knot styles, dtypes, table sizes (LDS-resident and L2-resident) and
+    derivative orders; evaluate, derivative and jacobian against the C oracle, on a batch that takes
+    the zero-copy host path and one that takes the staged path."""
+    rng = np.random.default_rng(20260)
+    checked = 0
+    for trial in range(70):
+        nind = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 5]))
+        omax_allowed = {1: 9, 2: 8, 3: 6, 4: 4, 5: 3}[nind]
+        if rng.random() < 0.4:
+            order = tuple([int(rng.integers(1, omax_allowed + 1))] * nind)
+        else:
+            order = tuple(int(rng.integers(1, omax_allowed + 1)) for _ in range(nind))
+        big = rng.random() < 0.25 and nind <= 3
+        lim = {1: 20000, 2: 260, 3: 42}[nind] if big else {1: 40, 2: 14, 3: 8, 4: 5, 5: 4}[nind]
+        ncoef = tuple(int(o + rng.integers(0, max(1, lim - o + 1))) for o in order)
+        if big:
+            ncoef = tuple(max(c, lim - 5) for c in ncoef)
+        ndep = int(rng.integers(1, 7))
+        dt = np.float32 if rng.random() < 0.3 else np.float64
+        if rng.random() < 0.5:
+            knots = [cases.clamped_uniform_knots(o, c, dt) for o, c in zip(order, ncoef)]
+        else:
+            knots = [cases.nonuniform_knots(rng, o, c, dt, -1.0, 2.0) for o, c in zip(order, ncoef)]
+        coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+        t = DeviceSpline(order, ncoef, knots, coefs, dt)
+        dom = [(float(k[o - 1]), float(k[c])) for k, o, c in zip(knots, order, ncoef)]
+        tol = 5e-5 if dt == np.float32 else 1e-11
+        for n in (257, 70_001):
+            pts = [(lo + (hi - lo) * rng.random(n)).astype(dt) for lo, hi in dom]
+            pts = [np.clip(p, dt(lo), dt(hi)) for p, (lo, hi) in zip(pts, dom)]
+            wrts = [[0] * nind, [int(rng.integers(0, 3)) for _ in range(nind)]]
+            for w in wrts:
+                got = t.evaluate(pts, w)
+                orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, pts)
+                assert bad == -1
+                assert np.abs(got - orc).max() <= tol * 30 * _scale(orc), (trial, order, ncoef, ndep, dt, n, w)
+            if n == 257 or nind <= 3:
+                got = t.jacobian(pts)
+                orc, _ = oracle.c_jacobian(order, ncoef, knots, coefs, pts)
+                assert np.abs(got - orc).max() <= tol * 30 * _scale(orc), (trial, order, ncoef, ndep, dt, n, "jac")
+            checked += 1
+        t.close()
+    assert checked == 140
