@@ -1392,6 +1392,45 @@ static bsk_status run_basis(int device, const T *knots, int nknots, int order, c
     std::vector<T> tab;
     build_axis_table<T>(knots, order, nknots, tab);
     const int ncoef = nknots - order;
+    if (n <= small_call_points()) {
+        // small calls (the reference's static Spline.bspline_values is one point): everything travels
+        // through one pinned, device-mapped buffer - no allocation, no staging copy, one synchronisation
+        static thread_local void *pin = nullptr;
+        static thread_local size_t pin_cap = 0;
+        auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+        const size_t o_tab = 0, o_u = o_tab + up(sizeof(T) * tab.size()), o_k = o_u + up(sizeof(T) * (size_t)n);
+        const size_t o_ix = o_k + up(sizeof(int) * (size_t)n), o_b = o_ix + up(sizeof(int) * (size_t)n);
+        const size_t total = o_b + up(sizeof(T) * (size_t)n * order);
+        if (total > pin_cap) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            pin_cap = 0;
+            HIPCHK(hipHostMalloc(&pin, total, hipHostMallocMapped | hipHostMallocPortable));
+            pin_cap = total;
+        }
+        char *hp = static_cast<char *>(pin);
+        void *dpv = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dpv, pin, 0));
+        char *dp = static_cast<char *>(dpv);
+        memcpy(hp + o_tab, tab.data(), sizeof(T) * tab.size());
+        memcpy(hp + o_u, u, sizeof(T) * (size_t)n);
+        if (knot_in) memcpy(hp + o_k, knot_in, sizeof(int) * (size_t)n);
+        // the axis table is read many times with dependent accesses (span search, recursion): it goes to
+        // device memory (one small DMA from the pinned buffer); parameters and results stay zero-copy
+        static thread_local DevBuf dtab_small;
+        HIPCHK(dtab_small.reserve(sizeof(T) * tab.size()));
+        HIPCHK(hipMemcpyAsync(dtab_small.p, hp + o_tab, sizeof(T) * tab.size(), hipMemcpyHostToDevice, 0));
+        const int blocks = (int)((n + 255) / 256);
+        hipLaunchKernelGGL((basis_rows<T>), dim3(blocks), dim3(256), 0, 0, static_cast<const T *>(dtab_small.p), nknots,
+                           order, ncoef, ceil_log2(ncoef - order + 1), reinterpret_cast<const T *>(dp + o_u), n, deriv, taylor,
+                           knot_in ? reinterpret_cast<const int *>(dp + o_k) : nullptr, reinterpret_cast<int *>(dp + o_ix),
+                           reinterpret_cast<T *>(dp + o_b), T(0), T(0), (unsigned char *)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(0));
+        memcpy(ix_out, hp + o_ix, sizeof(int) * (size_t)n);
+        memcpy(basis_out, hp + o_b, sizeof(T) * (size_t)n * order);
+        return BSK_OK;
+    }
     DevBuf dtab, du, dk, dix, db;
     auto release = [&]() { dtab.release(); du.release(); dk.release(); dix.release(); db.release(); };
 #define HIPCHK_R(expr)                                                                        \

@@ -23,3 +23,8 @@ for name, f in (("Spline.evaluate([u, v]) single point", lambda: s.evaluate([0.3
     t0 = time.perf_counter()
     for _ in range(500): f()
     print(f"{name}: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per call")
+k = np.concatenate((np.zeros(4), np.linspace(0, 1, 30)[1:-1], np.ones(4)))
+for _ in range(50): Spline.bspline_values(None, k, 4, 0.37)
+t0 = time.perf_counter()
+for _ in range(500): Spline.bspline_values(None, k, 4, 0.37)
+print(f"Spline.bspline_values(None, knots, 4, u) single point: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per call")
