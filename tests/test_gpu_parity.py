@@ -896,3 +896,17 @@ def test_random_shapes_against_oracle():
             checked += 1
         t.close()
     assert checked == 140
+
+
+def test_tessellate_more_patches_than_one_launch_takes():
+    """bsk_tessellate passes at most 64 coefficient pointers per launch: 70 patches take two."""
+    rng = np.random.default_rng(8)
+    ku, kv = cases.clamped_uniform_knots(3, 5), cases.clamped_uniform_knots(4, 6)
+    tabs = [DeviceSpline((3, 4), (5, 6), [ku, kv], rng.standard_normal((3, 5, 6))) for _ in range(70)]
+    u, v = np.linspace(0, 1, 9), np.linspace(0, 1, 12)
+    pos, nrm = bspy_amd.tessellate_tables(tabs, (u, v))
+    assert pos.shape == (70, 3, 9, 12)
+    for p in (0, 63, 64, 69):
+        assert np.abs(tabs[p].evaluate_grid([u, v]) - pos[p]).max() <= 1e-13
+        uu, vv = [a.ravel() for a in np.meshgrid(u, v, indexing="ij")]
+        assert np.abs(tabs[p].normal([uu, vv]).reshape(3, 9, 12) - nrm[p]).max() <= 1e-10
