@@ -1163,19 +1163,28 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
     const long long chunk = mem == BSK_HOST ? std::min(n, host_chunk_points()) : n;
     // jacobian workspace (device) for one chunk, unless the normal is fused into the jacobian kernel
     const bool fused = s->nDep == 3 && rowrot_applies<T>(s);
+    // one chunk of m points on stream ks (jacobian workspace in aux_ws when the normal is not fused)
+    auto normal_chunk = [&](const Params<T> &prm, long long m, T *dout, hipStream_t ks) -> bsk_status {
+        if (fused) return launch_jac_rowrot<T, true>(s, prm, m, dout, normalize, negate, ks);
+        T *dj = static_cast<T *>(s->aux_ws.p);
+        const bsk_status r = dispatch_jac<T>(s, prm, m, dj, ks);
+        if (r != BSK_OK) return r;
+        const int grid = (int)std::max<long long>(1, std::min<long long>((m + 255) / 256, (long long)s->num_cu * 8));
+        hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(256), 0, ks, dj, s->nInd, s->nDep, m, normalize, negate, dout);
+        HIPCHK(hipGetLastError());
+        return BSK_OK;
+    };
     if (mem == BSK_HOST && n <= small_call_points()) {
         if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)n * s->nDep * s->nInd));
-        return run_small<T>(s, uvw, n, big, out, st, first_bad, [&](const Params<T> &prm, T *dout) -> bsk_status {
-            if (fused) return launch_jac_rowrot<T, true>(s, prm, n, dout, normalize, negate, st);
-            T *dj = static_cast<T *>(s->aux_ws.p);
-            const bsk_status r = dispatch_jac<T>(s, prm, n, dj, st);
-            if (r != BSK_OK) return r;
-            const int grid = (int)std::max<long long>(1, (n + 255) / 256);
-            hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(256), 0, st, dj, s->nInd, s->nDep, n, normalize,
-                               negate, dout);
-            HIPCHK(hipGetLastError());
-            return BSK_OK;
-        });
+        return run_small<T>(s, uvw, n, big, out, st, first_bad,
+                            [&](const Params<T> &prm, T *dout) { return normal_chunk(prm, n, dout, st); });
+    }
+    if (mem == BSK_HOST && n >= PIPE_MIN_POINTS) {
+        if (CopyPool *pool = copy_pool()) {
+            if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)PIPE_CHUNK * s->nDep * s->nInd));
+            HIPCHK(hipStreamSynchronize(st));
+            return run_piped<T>(s, pool, uvw, n, big, out, first_bad, normal_chunk);
+        }
     }
     if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
     T *djac = static_cast<T *>(s->aux_ws.p);

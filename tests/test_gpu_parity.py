@@ -316,6 +316,10 @@ def test_full_size_properties():
     assert t.evaluate([uv[0], uv[1]], out=reuse) is reuse and np.array_equal(reuse, out)
     with pytest.raises(ValueError):
         t.evaluate([uv[0], uv[1]], out=np.empty((3, n), np.float32))
+    # (b'') the batched normal of the whole batch (pipelined host path) against the oracle on the sample
+    nrm = t.normal([uv[0], uv[1]])
+    onrm, _ = oracle.c_normal(order, ncoef, knots, coefs, [uv[0][idx], uv[1][idx]], True, False)
+    assert np.abs(nrm[:, idx] - onrm).max() <= 1e-10
     # (c) permutation equivariance, bitwise (no dependence on a point's position in the batch)
     perm = rng.permutation(n)
     assert np.array_equal(out[:, perm], t.evaluate([uv[0][perm], uv[1][perm]]))
