@@ -512,6 +512,10 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
         assert bad == -1
         assert np.abs(out[:, sample] - orc).max() <= tol * _scale(orc), (shape, w)
     assert np.array_equal(out, t.evaluate(pts, w))                       # second run: same bits
+    # the jacobian of such a batch = nInd derivative passes through the same pipeline
+    jac = t.jacobian(pts)
+    ojac, _ = oracle.c_jacobian(order, ncoef, knots, coefs, [p[sample] for p in pts])
+    assert np.abs(jac[:, :, sample] - ojac).max() <= 10 * tol * _scale(ojac), shape
     bad = [p.copy() for p in pts]
     bad[1][123_456] = dt(7.0)
     bad[0][250_000] = dt(-9.0)
