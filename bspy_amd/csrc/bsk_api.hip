@@ -87,8 +87,26 @@ static bsk_status upload_tables(bsk_spline s, const void *const *knots, const vo
         build_axis_table<T>(k, s->order[iv], d.nk[iv], tab);
         d.lo[iv] = k[s->order[iv] - 1];          // domain: reference _spline_evaluation.py:135-138
         d.hi[iv] = k[s->ncoef[iv]];
+        // bucket table: lut_buckets() entries are reserved (4 x spans); the smallest power of two >= spans is
+        // used when its brackets still hold at most two spans (every near-uniform knot vector): fewer
+        // distinct entries per LDS bank = fewer bank conflicts in the span search
         td.lut_off[iv] = (int)lut.size();
-        build_lut<T>(k, s->order[iv], s->ncoef[iv], td.lut_m[iv], td.lut_scale[iv], td.lut_steps[iv], lut);
+        const int m_alloc = lut_buckets(s->order[iv], s->ncoef[iv]);
+        int m_small = 16;
+        while (m_small < s->ncoef[iv] - s->order[iv] + 1) m_small <<= 1;
+        std::vector<unsigned> seg;
+        int m_use = m_alloc;
+        if (m_small < m_alloc) {
+            build_lut<T>(k, s->order[iv], s->ncoef[iv], m_small, td.lut_scale[iv], td.lut_steps[iv], seg);
+            if (td.lut_steps[iv] <= 1) m_use = m_small;
+        }
+        if (m_use == m_alloc) {
+            seg.clear();
+            build_lut<T>(k, s->order[iv], s->ncoef[iv], m_alloc, td.lut_scale[iv], td.lut_steps[iv], seg);
+        }
+        td.lut_m[iv] = m_use;
+        seg.resize((size_t)m_alloc, seg.empty() ? 0u : seg.back());
+        lut.insert(lut.end(), seg.begin(), seg.end());
     }
     if ((int)tab.size() != d.tab_len) return fail(BSK_ERR_INVALID, "internal: axis table size changed");
     if ((int)lut.size() != td.lut_len) return fail(BSK_ERR_INVALID, "internal: bucket table size changed");
@@ -139,7 +157,7 @@ static bsk_status init_desc(bsk_spline s)
     TileDesc<T> &td = tile_of<T>(s);
     memset(&td, 0, sizeof(td));
     for (int iv = 0; iv < s->nInd; ++iv) {
-        td.lut_m[iv] = lut_buckets(s->order[iv], s->ncoef[iv]);
+        td.lut_m[iv] = lut_buckets(s->order[iv], s->ncoef[iv]);   // reserved size; upload_tables may use fewer buckets
         td.lut_len += td.lut_m[iv];
     }
     auto up16 = [](size_t b) { return (unsigned)((b + 15) & ~(size_t)15); };

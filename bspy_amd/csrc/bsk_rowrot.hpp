@@ -42,7 +42,7 @@ namespace bsk {
 constexpr unsigned RR_MAX_CHUNK = 1u << 28;   // points per launch (32-bit byte offsets: 8 B * 2^28 = 2 GiB)
 
 // LDS image of the rowrot kernels (bytes, 16-byte aligned parts):
-//   [axis records: (nk0 + nk1) x (O | 1) x T] [bucket entries: lut_len x RrLutEntry] [coefficients, odd row
+//   [axis records: (nk0 + nk1) x (O | 1) x T] [bucket tables: lut_len x u32] [coefficients, odd row
 //   stride] [rank counters]
 template <typename T, int O>
 __host__ __device__ constexpr unsigned rr_rec_bytes() { return (unsigned)((O | 1) * sizeof(T)); }
@@ -53,43 +53,10 @@ __host__ __device__ inline unsigned rr_records_bytes(int nk0, int nk1)
     return ((unsigned)(nk0 + nk1) * rr_rec_bytes<T, O>() + 15u) & ~15u;
 }
 
-// Bucket-table entry of the rowrot image: the packed bracket (lo | hi << 16, see build_lut) and the
-// knot at lo, so the one-compare search needs a single LDS round trip (one 16- / 8-byte read).
-template <typename T>
-struct RrLutEntry;
-template <>
-struct RrLutEntry<double> {
-    unsigned e, pad;
-    double km;
-    typedef unsigned raw __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ raw read(unsigned addr)
-    {
-        raw r;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-        return r;
-    }
-    static __device__ __forceinline__ double knot(const raw &r)
-    {
-        return __hiloint2double((int)r.w, (int)r.z);
-    }
-};
-template <>
-struct RrLutEntry<float> {
-    unsigned e;
-    float km;
-    typedef unsigned raw __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ raw read(unsigned addr)
-    {
-        raw r;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-        return r;
-    }
-    static __device__ __forceinline__ float knot(const raw &r) { return __uint_as_float(r.y); }
-};
 template <typename T>
 __host__ __device__ inline unsigned rr_lut_bytes(int lut_len)
 {
-    return ((unsigned)lut_len * (unsigned)sizeof(RrLutEntry<T>) + 15u) & ~15u;
+    return ((unsigned)lut_len * (unsigned)sizeof(unsigned) + 15u) & ~15u;
 }
 
 // Copy the table image into LDS with several global loads in flight per lane (the plain
@@ -104,7 +71,7 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
     constexpr int REC = O | 1;
     const unsigned rec_bytes = rr_records_bytes<T, O>(d.nk[0], d.nk[1]);
     T *srec = reinterpret_cast<T *>(smem);
-    RrLutEntry<T> *slut = reinterpret_cast<RrLutEntry<T> *>(smem + rec_bytes);
+    unsigned *slut = reinterpret_cast<unsigned *>(smem + rec_bytes);
     T *scoef = reinterpret_cast<T *>(smem + rec_bytes + rr_lut_bytes<T>(td.lut_len));
     constexpr int U = 8;
     const int bd = blockDim.x;
@@ -128,12 +95,7 @@ __device__ __forceinline__ void stage_image_rowrot(char *smem, const Desc<T> &d,
             r[k * REC + D] = t[i];
         }
     }
-    for (int i = threadIdx.x; i < td.lut_len; i += bd) {
-        const unsigned e = glut[i];
-        const int iv = i >= td.lut_off[1] ? 1 : 0;
-        slut[i].e = e;
-        slut[i].km = gtab[d.off[iv] + (int)(e & 0xffffu)];
-    }
+    for (int i = threadIdx.x; i < td.lut_len; i += bd) slut[i] = glut[i];
 }
 
 // Reads of one variable's span from its records, base rb = address of record ix - (O - 1):
@@ -182,23 +144,25 @@ __device__ __forceinline__ void rr_find_spans(const unsigned (&rec_a)[2], unsign
                                               const TileDesc<T> &td, int steps, const T (&u)[2], int (&ix)[2])
 {
     constexpr unsigned RB = rr_rec_bytes<T, O>();
-    constexpr unsigned EB = (unsigned)sizeof(RrLutEntry<T>);
-    typename RrLutEntry<T>::raw e[2];
+    unsigned e[2];
 #pragma unroll
     for (int iv = 0; iv < 2; ++iv) {
         int b = (int)((u[iv] - d.lo[iv]) * td.lut_scale[iv]);
         b = min(max(b, 0), td.lut_m[iv] - 1);
-        e[iv] = RrLutEntry<T>::read(lut_a + EB * (unsigned)td.lut_off[iv] + EB * (unsigned)b);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(e[iv]) : "v"(lut_a + 4u * (unsigned)td.lut_off[iv] + 4u * (unsigned)b) : "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]) : : "memory");
+    lds_wait_n<0, 2>(e);
     int l[2], h[2];
 #pragma unroll
-    for (int iv = 0; iv < 2; ++iv) { l[iv] = (int)(e[iv].x & 0xffffu); h[iv] = (int)(e[iv].x >> 16); }
+    for (int iv = 0; iv < 2; ++iv) { l[iv] = (int)(e[iv] & 0xffffu); h[iv] = (int)(e[iv] >> 16); }
     if (steps == 1) {
-        // every bracket holds at most two spans: one compare against the knot between them,
-        // which came with the bucket entry
+        // every bracket holds at most two spans: one compare against the knot between them
+        T km[2];
 #pragma unroll
-        for (int iv = 0; iv < 2; ++iv) l[iv] += (int)((l[iv] < h[iv]) & (RrLutEntry<T>::knot(e[iv]) <= u[iv]));
+        for (int iv = 0; iv < 2; ++iv) km[iv] = LdsRead<T>::template at<0>(rec_a[iv] + __umul24((unsigned)l[iv], RB));
+        lds_wait_n<0, 2>(km);
+#pragma unroll
+        for (int iv = 0; iv < 2; ++iv) l[iv] += (int)((l[iv] < h[iv]) & (km[iv] <= u[iv]));
     } else {
         for (int s = 0; s < steps; ++s) {
             T km[2];
