@@ -934,3 +934,36 @@ def test_tessellate_more_patches_than_one_launch_takes():
         assert np.abs(tabs[p].evaluate_grid([u, v]) - pos[p]).max() <= 1e-13
         uu, vv = [a.ravel() for a in np.meshgrid(u, v, indexing="ij")]
         assert np.abs(tabs[p].normal([uu, vv]).reshape(3, 9, 12) - nrm[p]).max() <= 1e-10
+
+
+def test_random_large_tables_against_oracle():
+    """Random L2-resident tables (nInd 1..3, equal or different orders <= 6, nDep 1..4, both dtypes):
+    the gather kernel on a small batch and the cell-order pipeline on a batch >= 2^18 points against
+    the C oracle."""
+    rng = np.random.default_rng(99)
+    for trial in range(14):
+        nind = int(rng.choice([1, 2, 2, 3, 3]))
+        if rng.random() < 0.5:
+            order = tuple([int(rng.integers(1, 7))] * nind)
+        else:
+            order = tuple(int(rng.integers(1, 7)) for _ in range(nind))
+        ndep = int(rng.integers(1, 5))
+        dt = np.float32 if rng.random() < 0.4 else np.float64
+        target = {1: 60_000, 2: 330, 3: 48}[nind]                 # enough coefficients to overflow the LDS
+        ncoef = tuple(int(max(o, target + rng.integers(-6, 7))) for o in order)
+        knots = [cases.nonuniform_knots(rng, o, c, dt, 0.0, 1.0) if rng.random() < 0.5 else cases.clamped_uniform_knots(o, c, dt)
+                 for o, c in zip(order, ncoef)]
+        coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+        assert coefs.nbytes > 170_000
+        t = DeviceSpline(order, ncoef, knots, coefs, dt)
+        tol = 5e-5 if dt == np.float32 else 1e-11
+        for n in (4_097, 270_001):
+            pts = [rng.random(n).astype(dt) for _ in range(nind)]
+            w = [int(rng.integers(0, 2)) for _ in range(nind)]
+            idx = rng.choice(n, 4_000, replace=False)
+            for ww in ([0] * nind, w):
+                got = t.evaluate(pts, ww)
+                orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, ww, [p[idx] for p in pts])
+                assert bad == -1
+                assert np.abs(got[:, idx] - orc).max() <= 30 * tol * _scale(orc), (trial, order, ncoef, ndep, dt, n, ww)
+        t.close()
