@@ -44,7 +44,7 @@ def cpu_baseline(order, ncoef, knots, coefs, sample):
     _, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [uv[0], uv[1]])
     t1 = time.perf_counter()
     assert bad == -1
-    npy = 20_000
+    npy = 100_000
     t2 = time.perf_counter()
     oracle.py_batch(order, ncoef, knots, coefs, [0, 0], [uv[0][:npy], uv[1][:npy]])
     t3 = time.perf_counter()
@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (reported beside the headline, N=1 only)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--spinup", type=int, default=300, help="untimed launches before warm-up (clock ramp)")
     args = ap.parse_args()
 
