@@ -967,3 +967,35 @@ def test_random_large_tables_against_oracle():
                 assert bad == -1
                 assert np.abs(got[:, idx] - orc).max() <= 30 * tol * _scale(orc), (trial, order, ncoef, ndep, dt, n, ww)
         t.close()
+
+
+def test_handle_lifecycle():
+    """Creating, using (every host path: zero-copy, staged, pipelined, cell-order workspace) and destroying
+    many handles leaves the device memory where it was."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(1)
+    c = CASES["cfg2_bicubic"]
+    u, v = rng.random(300_000), rng.random(300_000)
+    big_order, big_ncoef = (3, 3), (300, 300)
+    bk = [cases.clamped_uniform_knots(o, n_) for o, n_ in zip(big_order, big_ncoef)]
+    bc = rng.standard_normal((2, *big_ncoef))
+    def cycle(i):
+        t = DeviceSpline(c.order, c.nCoef, c.knots, c.coefs)
+        t.evaluate([u[:10], v[:10]])                      # zero-copy path
+        t.evaluate([u, v])                                # staged path
+        if i % 8 == 0:
+            t.jacobian([np.tile(u, 8), np.tile(v, 8)])    # pipelined path (2.4 M points)
+        t.close()
+        b = DeviceSpline(big_order, big_ncoef, bk, bc)
+        b.evaluate([u, v])                                # cell-order workspace
+        b.close()
+
+    for i in range(3):                                    # first use: code objects, runtime pools
+        cycle(0)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(40):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 << 20, (free0, free1)
