@@ -24,93 +24,93 @@ def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch"
 
 
-class SplineBlock:
-    """Same constructor semantics as the reference (bspy/spline_block.py:54-113)."""
+def _looks_like_spline(x):
+    return all(hasattr(x, a) for a in ("nInd", "nDep", "order", "nCoef", "knots", "coefs"))
 
-    @staticmethod
-    def _map_args(map, args):
-        # reference spline_block.py:33-35
-        return [arg[map] if isinstance(arg, np.ndarray) else [arg[index] for index in map] for arg in args]
+
+def _select(index_map, values):
+    """The entries of ``values`` a spline sees through its variable map."""
+    if isinstance(values, np.ndarray):
+        return values[index_map]
+    return [values[i] for i in index_map]
+
+
+class SplineBlock:
+    """System of equations made of splines: rows are stacked, the splines of a row are summed.
+    Same constructor semantics, attributes (``block``, ``nInd``, ``nDep``, ``knotsDtype``,
+    ``coefsDtype``, ``size``) and error messages as the reference (bspy/spline_block.py:54-113)."""
 
     def __init__(self, block):
-        from .spline import Spline
-        is_spline = lambda s: isinstance(s, Spline) or all(hasattr(s, a) for a in ("nInd", "nDep", "order", "nCoef", "knots", "coefs"))
-        if is_spline(block):
-            block = [[block]]
-        elif is_spline(block[0]) or (len(block) > 1 and is_spline(block[1])):
-            block = [block]
+        # a bare spline is a 1 x 1 block, a flat list of splines one row (reference :55-58)
+        if _looks_like_spline(block):
+            rows = [[block]]
+        elif _looks_like_spline(block[0]) or (len(block) > 1 and _looks_like_spline(block[1])):
+            rows = [block]
+        else:
+            rows = block
 
         self.block = []
-        self.nInd = 0
-        self.nDep = 0
-        self.knotsDtype = None
-        self.coefsDtype = None
-        self.size = 0
-        domain = {}
-        for row in block:
-            row_dep = 0
-            row_ind = 0
-            used = set()
-            new_row = []
-            for entry in row:
-                if is_spline(entry):
-                    spline = entry
-                    imap = list(range(row_ind, row_ind + spline.nInd))
+        self.knotsDtype = self.coefsDtype = None
+        self.nDep = self.size = 0
+        bounds = {}                                   # block variable -> (lower, upper), first claim wins
+
+        def claim(variable, lower, upper, taken):
+            if variable in taken:
+                raise ValueError(f"Multiple splines in the same row map to independent variable {variable}")
+            taken.add(variable)
+            known = bounds.setdefault(variable, (lower, upper))
+            if known[0] != lower or known[1] != upper:
+                raise ValueError("Domains of independent variables must match")
+
+        for row in rows:
+            entries, taken, row_dep, next_default = [], set(), None, 0
+            for item in row:
+                if _looks_like_spline(item):            # default map: consecutive variables along the row
+                    spline, index_map = item, list(range(next_default, next_default + item.nInd))
                 else:
-                    imap, spline = entry
-                    imap = list(imap)
-                row_ind += spline.nInd
-                if row_dep == 0:
+                    index_map, spline = list(item[0]), item[1]
+                next_default += spline.nInd
+                if not row_dep:
                     row_dep = spline.nDep
-                    if self.nDep == 0:
-                        self.knotsDtype = spline.knots[0].dtype
-                        self.coefsDtype = spline.coefs.dtype
-                elif row_dep != spline.nDep:
+                    if self.nDep == 0:                  # the first spline fixes the block's dtypes
+                        self.knotsDtype, self.coefsDtype = spline.knots[0].dtype, spline.coefs.dtype
+                elif spline.nDep != row_dep:
                     raise ValueError("All splines in the same row must have the same nDep")
-                d = _se.domain(spline)
-                for ind, i in enumerate(imap):
-                    if i in used:
-                        raise ValueError(f"Multiple splines in the same row map to independent variable {i}")
-                    used.add(i)
-                    if i in domain:
-                        if domain[i][0] != d[ind, 0] or domain[i][1] != d[ind, 1]:
-                            raise ValueError("Domains of independent variables must match")
-                    else:
-                        domain[i] = d[ind]
-                new_row.append((imap, spline))
-            if row_dep > 0:
+                for (lower, upper), variable in zip(_se.domain(spline), index_map):
+                    claim(variable, lower, upper, taken)
+                entries.append((index_map, spline))
+            if row_dep:
+                self.block.append(entries)
                 self.nDep += row_dep
                 self.size += len(row)
-                self.block.append(new_row)
 
-        self.nInd = len(domain)
-        dom = []
-        for i in range(self.nInd):
-            if i not in domain:
-                raise ValueError(f"Block is missing independent variable {i}")
-            dom.append(domain[i])
-        self._domain = np.array(dom, self.knotsDtype)
-
-    def __call__(self, uvw):
-        return self.evaluate(uvw)
+        self.nInd = len(bounds)
+        missing = [v for v in range(self.nInd) if v not in bounds]
+        if missing:
+            raise ValueError(f"Block is missing independent variable {missing[0]}")
+        self._domain = np.array([bounds[v] for v in range(self.nInd)], self.knotsDtype)
 
     def __repr__(self):
         return f"SplineBlock({self.block})"
+
+    def __call__(self, uvw):
+        return self.evaluate(uvw)
 
     def domain(self):
         """nInd x 2 array of lower / upper bounds (reference spline_block.py:199-208)."""
         return self._domain
 
     # ------------------------------------------------------------------ single point (reference API)
-    def _block_evaluation(self, function, args):
-        # reference spline_block.py:37-44
-        value = np.zeros(self.nDep, self.coefsDtype)
-        n_dep = 0
-        for row in self.block:
-            for imap, spline in row:
-                value[n_dep:n_dep + spline.nDep] += function(spline, *SplineBlock._map_args(imap, args))
-            n_dep += spline.nDep
-        return value
+    def _sum_rows(self, point_function, *arguments):
+        """Every row's splines evaluated on their mapped arguments and summed (reference :37-44)."""
+        total = np.zeros(self.nDep, self.coefsDtype)
+        first = 0
+        for entries in self.block:
+            width = entries[0][1].nDep
+            for index_map, spline in entries:
+                total[first:first + width] += point_function(spline, *[_select(index_map, a) for a in arguments])
+            first += width
+        return total
 
     @staticmethod
     def _is_batch(uvw):
@@ -121,27 +121,28 @@ class SplineBlock:
         spline_block.py:210-224).  Arrays / CUDA tensors per variable -> ``(nDep, *shape)``."""
         if self._is_batch(uvw):
             return self._batch(None, uvw)
-        return self._block_evaluation(_se.evaluate, (uvw,))
+        return self._sum_rows(_se.evaluate, uvw)
 
     def derivative(self, with_respect_to, uvw):
         """Derivative of the block (reference spline_block.py:179-197)."""
         if self._is_batch(uvw):
             return self._batch([int(w) for w in with_respect_to], uvw)
-        return self._block_evaluation(_se.derivative, (with_respect_to, uvw))
+        return self._sum_rows(_se.derivative, with_respect_to, uvw)
 
     def jacobian(self, uvw):
         """(nDep, nInd) jacobian at one point (reference spline_block.py:226-247); arrays /
         CUDA tensors per variable -> ``(nDep, nInd, *shape)``."""
         if self._is_batch(uvw):
             return self._batch_jacobian(uvw)
-        jac = np.zeros((self.nDep, self.nInd), self.coefsDtype)
-        uvw = np.atleast_1d(uvw)
-        n_dep = 0
-        for row in self.block:
-            for imap, spline in row:
-                jac[n_dep:n_dep + spline.nDep, imap] += _se.jacobian(spline, uvw[imap])
-            n_dep += spline.nDep
-        return jac
+        point = np.atleast_1d(uvw)
+        result = np.zeros((self.nDep, self.nInd), self.coefsDtype)
+        first = 0
+        for entries in self.block:
+            width = entries[0][1].nDep
+            for index_map, spline in entries:
+                result[first:first + width, index_map] += _se.jacobian(spline, point[index_map])
+            first += width
+        return result
 
     # ------------------------------------------------------------------ batched (GPU resident)
     def _device_points(self, uvw):
