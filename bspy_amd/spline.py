@@ -45,36 +45,39 @@ class Spline:
     (constructor semantics of the reference, bspy/spline.py:46-76)."""
 
     def __init__(self, nInd, nDep, order, nCoef, knots, coefs, metadata={}):
-        if not (nInd >= 0): raise ValueError("nInd < 0")
-        self.nInd = int(nInd)
-        if not (nDep >= 0): raise ValueError("nDep < 0")
-        self.nDep = int(nDep)
-        if not (len(order) == self.nInd): raise ValueError("len(order) != nInd")
-        self.order = tuple(int(x) for x in order)
-        if not (len(nCoef) == self.nInd): raise ValueError("len(nCoef) != nInd")
-        self.nCoef = tuple(int(x) for x in nCoef)
-        if not (len(knots) == nInd): raise ValueError("len(knots) != nInd")
-        for i in range(len(knots)):
-            nKnots = self.order[i] + self.nCoef[i]
-            if not (len(knots[i]) == nKnots):
-                raise ValueError(f"Knots array for variable {i} should have length {nKnots}")
-        self.knots = tuple(_as_float_array(kk) for kk in knots)
-        for kk, o, n in zip(self.knots, self.order, self.nCoef):
-            # knots[i] <= knots[i+1] and knots[i+order] - knots[i] > 0 for i < nCoef (spline.py:61-64)
-            if n > 0 and not (np.all(kk[:n] <= kk[1:n + 1]) and np.all(kk[o:o + n] - kk[:n] > 0)):
-                raise ValueError("Improper knot order or multiplicity")
-        totalCoefs = 1
-        for n in self.nCoef:
-            totalCoefs *= n
-        if not (len(coefs) == totalCoefs or len(coefs) == self.nDep):
-            raise ValueError(f"Length of coefs should be {totalCoefs} or {self.nDep}")
-        self.coefs = _as_float_array(coefs)
-        if self.coefs.shape != (self.nDep, *self.nCoef):
-            if len(self.coefs) == totalCoefs:
+        # argument checks in the reference's order, with its messages (spline.py:47-69)
+        def need(ok, message):
+            if not ok:
+                raise ValueError(message)
+
+        need(nInd >= 0, "nInd < 0")
+        need(nDep >= 0, "nDep < 0")
+        self.nInd, self.nDep = int(nInd), int(nDep)
+        need(len(order) == self.nInd, "len(order) != nInd")
+        need(len(nCoef) == self.nInd, "len(nCoef) != nInd")
+        self.order = tuple(map(int, order))
+        self.nCoef = tuple(map(int, nCoef))
+        need(len(knots) == nInd, "len(knots) != nInd")
+        for variable, (kv, o, n) in enumerate(zip(knots, self.order, self.nCoef)):
+            need(len(kv) == o + n, f"Knots array for variable {variable} should have length {o + n}")
+        self.knots = tuple(_as_float_array(kv) for kv in knots)
+        for kv, o, n in zip(self.knots, self.order, self.nCoef):
+            # non-decreasing over the first nCoef + 1 knots, and every basis function has support
+            # (knots[i + order] > knots[i]), reference spline.py:61-64
+            proper = n == 0 or (bool(np.all(np.diff(kv[:n + 1]) >= 0)) and bool(np.all(kv[o:o + n] > kv[:n])))
+            need(proper, "Improper knot order or multiplicity")
+        points = int(np.prod(self.nCoef, dtype=np.int64)) if self.nCoef else 1
+        need(len(coefs) in (points, self.nDep), f"Length of coefs should be {points} or {self.nDep}")
+        table = _as_float_array(coefs)
+        canonical = (self.nDep, *self.nCoef)
+        if table.shape != canonical:
+            if len(table) == points:
                 # flat "list of points" form: nDep fastest, then the FIRST variable (spline.py:72-73)
-                self.coefs = self.coefs.reshape((*self.nCoef[::-1], self.nDep)).T
+                table = table.reshape((*reversed(self.nCoef), self.nDep)).T
             else:
-                self.coefs = np.array([c.T for c in self.coefs]).reshape((self.nDep, *self.nCoef))
+                # one array per dependent variable, each stored last-variable-first (spline.py:74-75)
+                table = np.stack([np.transpose(component) for component in table]).reshape(canonical)
+        self.coefs = table
         self.metadata = dict(metadata)
 
     def __call__(self, *uvw, **kwargs):
@@ -168,13 +171,12 @@ class Spline:
     def from_dict(dictionary):
         """Spline from a `dict` as written by `to_dict` / the reference's files, including the
         legacy "flipNormal" metadata key (reference spline.py:1099-1125)."""
-        spline = Spline(dictionary["nInd"], dictionary["nDep"], dictionary["order"], dictionary["nCoef"],
-                        [np.array(knots) for knots in dictionary["knots"]], np.array(dictionary["coefs"]),
-                        dictionary.get("metadata", {}))
-        if spline.metadata.get("flipNormal", False):
-            spline.metadata["negateNormal"] = True
-            del spline.metadata["flipNormal"]
-        return spline
+        d = dictionary
+        meta = dict(d.get("metadata", {}))
+        if meta.pop("flipNormal", False):              # legacy name of negateNormal
+            meta["negateNormal"] = True
+        return Spline(d["nInd"], d["nDep"], d["order"], d["nCoef"], [np.asarray(k) for k in d["knots"]],
+                      np.asarray(d["coefs"]), meta)
 
     @staticmethod
     def load(fileName):
@@ -182,29 +184,32 @@ class Spline:
         objects, nested `coefs` of shape (nDep, *nCoef) (reference spline.py:1542-1583; the
         legacy .npz branch is not supported)."""
         import json
-        with open(fileName, "r", encoding="utf-8") as file:
-            data = json.load(file)
-        if isinstance(data, dict):
-            data = [data]
-        return [Spline.from_dict(d) for d in data if d.get("type", "Spline") == "Spline"]
+        with open(fileName, "r", encoding="utf-8") as stream:
+            content = json.load(stream)
+        records = [content] if isinstance(content, dict) else content
+        return [Spline.from_dict(r) for r in records if r.get("type", "Spline") == "Spline"]
 
     def save(self, fileName, *additional_splines):
-        """Write this spline (and more) as JSON in the reference's format (spline.py:1998-2026)."""
+        """Write this spline (and more) as JSON in the reference's format (spline.py:1998-2026):
+        one object, or a list when more splines are given; arrays as nested lists, indent 4."""
         import json
 
-        class SplineEncoder(json.JSONEncoder):
-            def default(self, obj):
-                if isinstance(obj, np.ndarray):
-                    return obj.tolist()
-                if isinstance(obj, Spline):
-                    return obj.to_dict()
-                return super().default(obj)
+        def plain(value):
+            if isinstance(value, Spline):
+                return plain(value.to_dict())
+            if isinstance(value, np.ndarray):
+                return value.tolist()
+            if isinstance(value, dict):
+                return {k: plain(v) for k, v in value.items()}
+            if isinstance(value, (list, tuple)):
+                return [plain(v) for v in value]
+            if isinstance(value, np.generic):
+                return value.item()
+            return value
 
-        with open(fileName, "w", encoding="utf-8") as file:
-            if additional_splines:
-                json.dump((self, *additional_splines), file, indent=4, cls=SplineEncoder)
-            else:
-                json.dump(self, file, indent=4, cls=SplineEncoder)
+        document = plain(self) if not additional_splines else [plain(s) for s in (self, *additional_splines)]
+        with open(fileName, "w", encoding="utf-8") as stream:
+            json.dump(document, stream, indent=4)
 
     # ------------------------------------------------------------------ device tables
     def device_tables(self, device=None):
