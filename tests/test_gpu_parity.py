@@ -880,9 +880,10 @@ def test_random_shapes_against_oracle():
     variable), nDep (1..6), knot styles, dtypes, table sizes (LDS-resident and L2-resident) and
     derivative orders; evaluate, derivative and jacobian against the C oracle, on a batch that takes
     the zero-copy host path and one that takes the staged path."""
-    rng = np.random.default_rng(20260)
+    trials = int(os.environ.get("BSK_SOAK", "70"))              # BSK_SOAK=1000 for a longer soak with another seed
+    rng = np.random.default_rng(20260 if trials == 70 else 777)
     checked = 0
-    for trial in range(70):
+    for trial in range(trials):
         nind = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 5]))
         omax_allowed = {1: 9, 2: 8, 3: 6, 4: 4, 5: 3}[nind]
         if rng.random() < 0.4:
@@ -919,7 +920,7 @@ def test_random_shapes_against_oracle():
                 assert np.abs(got - orc).max() <= tol * 30 * _scale(orc), (trial, order, ncoef, ndep, dt, n, "jac")
             checked += 1
         t.close()
-    assert checked == 140
+    assert checked == 2 * trials
 
 
 def test_tessellate_more_patches_than_one_launch_takes():
