@@ -24,7 +24,7 @@ SYMBOLS = (
     "bsk_version", "bsk_last_error", "bsk_device_count",
     "bsk_spline_create", "bsk_spline_update", "bsk_spline_destroy",
     "bsk_evaluate", "bsk_jacobian", "bsk_normal", "bsk_curvature", "bsk_evaluate_grid", "bsk_tessellate",
-    "bsk_domain_status", "bsk_bspline_values",
+    "bsk_domain_status", "bsk_bspline_values", "bsk_last_kernel", "bsk_debug_probe",
 )
 
 
@@ -96,8 +96,11 @@ def lib():
     L.bsk_domain_status.argtypes = [_vp, _vp, _i64p]
     L.bsk_bspline_values.argtypes = [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _i64,
                                      ctypes.c_int, ctypes.c_int, _i32p, _i32p, _vp]
+    L.bsk_last_kernel.argtypes = [_vp]
+    L.bsk_last_kernel.restype = ctypes.c_char_p
+    L.bsk_debug_probe.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, _vp, _vp, _i64, _vp, _vp]
     for name in SYMBOLS:
-        if name not in ("bsk_version", "bsk_last_error"):
+        if name not in ("bsk_version", "bsk_last_error", "bsk_last_kernel"):
             getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L

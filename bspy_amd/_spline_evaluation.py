@@ -35,50 +35,56 @@ def compute_dtype(self):
     return np.dtype(np.float64)
 
 
-_MIX_WEIGHTS = {}
+def _bits(arr):
+    """The array's bytes as unsigned integers of its own item size (NaN payloads and signed zeros
+    compare like any other bit pattern)."""
+    a = np.ascontiguousarray(arr)
+    return a.reshape(-1).view(f"u{a.dtype.itemsize}") if a.dtype.itemsize in (4, 8) else a.reshape(-1).view(np.uint8)
 
 
-def _mix(arr):
-    """Position-sensitive 64-bit hash of an array's bytes: sum of the 8-byte words times fixed odd
-    multipliers, mod 2^64 (vectorised: ~5 us for the 96 KB of a 64 x 64 x 3 table where adler32
-    takes ~40 us - this runs on every call, single-point calls included)."""
-    b = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
-    n8 = b.size // 8
-    w = b[:n8 * 8].view(np.uint64)
-    m = _MIX_WEIGHTS.get(n8)
-    if m is None:
-        m = np.random.default_rng(0x5EED + n8).integers(0, 2 ** 63, n8, dtype=np.uint64)
-        m = m * np.uint64(2) + np.uint64(1)
-        _MIX_WEIGHTS[n8] = m
-    h = int(np.dot(w, m))                       # integer dot product: wraps mod 2^64, no temporary
-    return (h, bytes(b[n8 * 8:])) if b.size != n8 * 8 else h
+def _layout(self):
+    return (self.coefs.shape, str(self.coefs.dtype), tuple((len(k), str(np.asarray(k).dtype)) for k in self.knots))
 
 
-def _fingerprint(self):
-    return (_mix(self.coefs), tuple(_mix(k) for k in self.knots), self.coefs.shape, str(self.coefs.dtype),
-            tuple(len(k) for k in self.knots))
+def _unchanged(snapshot, self):
+    """Exact comparison of knots and coefficients with the private copies taken at upload time (a
+    96 KB table compares in ~6 us; a checksum cheap enough to run on every call would be a linear
+    one, which misses swaps of round values)."""
+    coefs, knots = snapshot
+    cb = _bits(self.coefs)
+    if cb.shape != coefs.shape or cb.dtype != coefs.dtype or not np.array_equal(cb, coefs):
+        return False
+    for k, snap in zip(self.knots, knots):
+        kb = _bits(k)
+        if kb.shape != snap.shape or kb.dtype != snap.dtype or not np.array_equal(kb, snap):
+            return False
+    return True
+
+
+def _snapshot(self):
+    return (_bits(self.coefs).copy(), tuple(_bits(k).copy() for k in self.knots))
 
 
 def device_tables(self, device=None):
     """The DeviceSpline of ``self`` on ``device`` (created on first use, cached on the
     object).  The reference's attributes are mutable (bspy/_spline_fitting.py:529-540
-    writes coefs in place), so the cache is validated against a checksum of knots and
-    coefs on every call and re-uploaded when they changed."""
+    writes coefs in place), so the cache is validated on every call against private copies of
+    knots and coefs (exact comparison) and the tables are re-uploaded when they changed."""
     device = get_device() if device is None else int(device)
     cache = self.__dict__.setdefault("_bsk_cache", {})
     dt = compute_dtype(self)
-    fp = _fingerprint(self)
+    layout = _layout(self)
     entry = cache.get(device)
-    if entry is not None and entry[1] == fp:
-        return entry[0]
-    if entry is not None and entry[1][2:] == fp[2:] and entry[0].dtype == dt:
+    if entry is not None and entry[1] == layout and entry[0].dtype == dt:
+        if _unchanged(entry[2], self):
+            return entry[0]
         entry[0].update(self.knots, self.coefs)
-        cache[device] = (entry[0], fp)
+        cache[device] = (entry[0], layout, _snapshot(self))
         return entry[0]
     if entry is not None:
         entry[0].close()
     tables = DeviceSpline(self.order, self.nCoef, self.knots, self.coefs, dt, device)
-    cache[device] = (tables, fp)
+    cache[device] = (tables, layout, _snapshot(self))
     return tables
 
 

@@ -4,6 +4,7 @@
 #include "bsk_tile.hpp"
 #include "bsk_stream.hpp"
 #include "bsk_rowrot.hpp"
+#include "bsk_uniform.hpp"
 #include "bsk_host.hpp"
 
 #include <condition_variable>
@@ -167,6 +168,9 @@ static bsk_status init_desc(bsk_spline s)
     return BSK_OK;
 }
 
+template <typename T>
+static bsk_status upload_uniform(bsk_spline s, const void *const *knots, const void *coefs);   // uniform-knot surface path
+
 extern "C" int bsk_version(void) { return BSK_VERSION; }
 extern "C" const char *bsk_last_error(void) { return g_err.c_str(); }
 
@@ -258,7 +262,8 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
     HIPCHK_C(hipMemset(s->bad, 0xff, sizeof(unsigned long long)));
 #undef HIPCHK_C
     st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
-    if (st != BSK_OK) { cleanup(); return st; }
+    if (st == BSK_OK) st = dtype == BSK_F32 ? upload_uniform<float>(s, knots, coefs) : upload_uniform<double>(s, knots, coefs);
+    if (st != BSK_OK) { s->uni_img.release(); cleanup(); return st; }
     *out = s;
     return BSK_OK;
 }
@@ -268,7 +273,9 @@ extern "C" bsk_status bsk_spline_update(bsk_spline s, const void *const *knots, 
     if (!s || !knots || !coefs) return fail(BSK_ERR_INVALID, "NULL argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
-    return s->dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
+    const bsk_status st = s->dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
+    if (st != BSK_OK) return st;
+    return s->dtype == BSK_F32 ? upload_uniform<float>(s, knots, coefs) : upload_uniform<double>(s, knots, coefs);
 }
 
 extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
@@ -285,6 +292,7 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->out_ws.release();
     s->aux_ws.release();
     s->bin_ws.release();
+    s->uni_img.release();
     if (s->pin) (void)hipHostFree(s->pin);
     s->pin = nullptr;
     pipe_destroy(s->pipe);
@@ -334,10 +342,12 @@ static bsk_status launch_eval_fixed(bsk_spline s, const Plan &p, const Params<T>
     const T *coef = static_cast<const T *>(s->coef);
     if (p.lds_coefs) {
         HIPCHK(allow_lds(eval_fixed<T, NIND, O, true>, p.lds_bytes));
+        s->last_kernel = "eval_fixed";
         hipLaunchKernelGGL((eval_fixed<T, NIND, O, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
     } else {
         HIPCHK(allow_lds(eval_fixed<T, NIND, O, false>, p.lds_bytes));
+        s->last_kernel = "eval_fixed";
         hipLaunchKernelGGL((eval_fixed<T, NIND, O, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
     }
@@ -360,6 +370,7 @@ static bsk_status launch_eval_mixed(bsk_spline s, const Plan &p, const Params<T>
     const T *coef = static_cast<const T *>(s->coef);
     if (p.lds_coefs) {
         HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, true>, p.lds_bytes));
+        s->last_kernel = "eval_mixed";
         hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
     } else if constexpr (NIND >= 4) {
@@ -368,6 +379,7 @@ static bsk_status launch_eval_mixed(bsk_spline s, const Plan &p, const Params<T>
         return launch_eval_generic<T>(s, prm, n, out, ostride, w, st);
     } else {
         HIPCHK(allow_lds(eval_mixed<T, NIND, OMAX, false>, p.lds_bytes));
+        s->last_kernel = "eval_mixed";
         hipLaunchKernelGGL((eval_mixed<T, NIND, OMAX, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, ostride, w, s->bad);
     }
@@ -384,10 +396,12 @@ static bsk_status launch_jac_fixed(bsk_spline s, const Plan &p, const Params<T> 
     const T *coef = static_cast<const T *>(s->coef);
     if (p.lds_coefs) {
         HIPCHK(allow_lds(jac_fixed<T, NIND, O, true>, p.lds_bytes));
+        s->last_kernel = "jac_fixed";
         hipLaunchKernelGGL((jac_fixed<T, NIND, O, true>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, s->bad);
     } else {
         HIPCHK(allow_lds(jac_fixed<T, NIND, O, false>, p.lds_bytes));
+        s->last_kernel = "jac_fixed";
         hipLaunchKernelGGL((jac_fixed<T, NIND, O, false>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef,
                            prm, n, out, s->bad);
     }
@@ -403,6 +417,7 @@ static bsk_status launch_eval_generic(bsk_spline s, const Params<T> &prm, long l
     const int block = 256;
     const long long blocks = (n + block - 1) / block;
     const int grid = (int)std::max<long long>(1, std::min<long long>(blocks, (long long)s->num_cu * 8));
+    s->last_kernel = "eval_generic";
     hipLaunchKernelGGL((eval_generic<T>), dim3(grid), dim3(block), 0, st, d, static_cast<const T *>(s->tab),
                        static_cast<const T *>(s->coef), prm, n, out, ostride, w, s->bad);
     HIPCHK(hipGetLastError());
@@ -454,6 +469,179 @@ static bool rowrot_applies(bsk_spline s)
            (s->variant == 0 || s->variant == 9) && rowrot_lds_bytes<T>(s) <= s->lds_max;
 }
 
+// ------------------------------------------------------------------------------------
+// uniform-knot surface path (bsk_uniform.hpp): detection, unclamping, LDS image
+// ------------------------------------------------------------------------------------
+// Domain knots equally spaced (within 4 ulp of the larger domain end), each end either clamped (order
+// equal knots) or continuing the uniform spacing.
+template <typename T>
+static bool axis_is_uniform(const T *k, int order, int ncoef, bool &clamp_lo, bool &clamp_hi)
+{
+    const int ns = ncoef - order + 1;
+    const long double lo = k[order - 1], hi = k[ncoef];
+    if (!(hi > lo) || ns < 1) return false;
+    const long double h = (hi - lo) / ns;
+    const long double tol = 4.0L * std::numeric_limits<T>::epsilon() * std::max(std::fabs(lo), std::fabs(hi));
+    for (int j = 0; j <= ns; ++j)
+        if (std::fabs((long double)k[order - 1 + j] - (lo + j * h)) > tol) return false;
+    auto side = [&](bool low, bool &clamped) {
+        bool cl = true, un = true;
+        for (int i = 1; i < order; ++i) {
+            const long double v = low ? (long double)k[order - 1 - i] : (long double)k[ncoef + i];
+            const long double e = low ? lo : hi;
+            if (v != e) cl = false;
+            if (std::fabs(v - (low ? lo - i * h : hi + i * h)) > tol) un = false;
+        }
+        clamped = cl && order > 1;
+        return cl || un;
+    };
+    return side(true, clamp_lo) && side(false, clamp_hi);
+}
+
+// Non-zero B-spline basis values at z on the span [kn[ix - 1], kn[ix]) (reference
+// bspy/_spline_evaluation.py:11-18), extended precision.
+static void host_basis(const long double *kn, int O, int ix, long double z, long double *b)
+{
+    for (int i = 0; i < O; ++i) b[i] = 0;
+    b[O - 1] = 1;
+    for (int degree = 1; degree < O; ++degree) {
+        int bi = O - degree;
+        for (int i = ix - degree; i < ix; ++i, ++bi) {
+            const long double alpha = (z - kn[i]) / (kn[i + degree] - kn[i]);
+            b[bi - 1] += (1 - alpha) * b[bi];
+            b[bi] *= alpha;
+        }
+    }
+}
+
+// Unclamping matrix of one end for order O: the first O control points Q of the uniform-knot form
+// from the first O control points P of the clamped form, Q = M P (only the first O - 1 change).
+// Both bases span the polynomials of degree < O on the first span, so M = U^-1 C with the two bases
+// sampled at O points; unit spans (the matrix does not depend on h).  The other end is the mirror image.
+static bool unclamp_matrix(int O, std::vector<long double> &M)
+{
+    std::vector<long double> kc(2 * O + 1), ku(2 * O + 1);
+    for (int i = 0; i <= 2 * O; ++i) { kc[i] = i < O ? 0 : i - O + 1; ku[i] = i - (O - 1); }
+    std::vector<long double> U((size_t)O * O), C((size_t)O * O), b(O);
+    for (int r = 0; r < O; ++r) {
+        const long double z = (r + 0.5L) / O;
+        host_basis(ku.data(), O, O, z, b.data());
+        for (int i = 0; i < O; ++i) U[(size_t)r * O + i] = b[i];
+        host_basis(kc.data(), O, O, z, b.data());
+        for (int i = 0; i < O; ++i) C[(size_t)r * O + i] = b[i];
+    }
+    // Gauss-Jordan with partial pivoting on [U | C]
+    for (int c = 0; c < O; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < O; ++r) if (std::fabs(U[(size_t)r * O + c]) > std::fabs(U[(size_t)piv * O + c])) piv = r;
+        if (U[(size_t)piv * O + c] == 0) return false;
+        if (piv != c) for (int i = 0; i < O; ++i) { std::swap(U[(size_t)piv * O + i], U[(size_t)c * O + i]); std::swap(C[(size_t)piv * O + i], C[(size_t)c * O + i]); }
+        const long double d = U[(size_t)c * O + c];
+        for (int i = 0; i < O; ++i) { U[(size_t)c * O + i] /= d; C[(size_t)c * O + i] /= d; }
+        for (int r = 0; r < O; ++r) {
+            if (r == c) continue;
+            const long double f = U[(size_t)r * O + c];
+            if (f == 0) continue;
+            for (int i = 0; i < O; ++i) { U[(size_t)r * O + i] -= f * U[(size_t)c * O + i]; C[(size_t)r * O + i] -= f * C[(size_t)c * O + i]; }
+        }
+    }
+    M = C;
+    return true;
+}
+
+// Apply Q = M P to the first (low) or last (mirrored) O control points of every line along variable iv
+// of the (lines_outer, nc, inner) tensor w.
+static void unclamp_axis(std::vector<long double> &w, size_t outer, int nc, size_t inner, int O,
+                         const std::vector<long double> &M, bool low)
+{
+    std::vector<long double> p(O);
+    for (size_t a = 0; a < outer; ++a)
+        for (size_t c = 0; c < inner; ++c) {
+            long double *line = w.data() + a * (size_t)nc * inner + c;
+            for (int i = 0; i < O; ++i) p[i] = line[(size_t)(low ? i : nc - 1 - i) * inner];
+            for (int i = 0; i < O; ++i) {
+                long double q = 0;
+                for (int j = 0; j < O; ++j) q += M[(size_t)i * O + j] * p[j];
+                line[(size_t)(low ? i : nc - 1 - i) * inner] = q;
+            }
+        }
+}
+
+template <typename T>
+static bool rowrot_applies(bsk_spline s);
+
+template <typename T>
+static bsk_status upload_uniform(bsk_spline s, const void *const *knots, const void *coefs)
+{
+    s->uni = false;
+    if (!rowrot_applies<T>(s) || s->variant == 9) return BSK_OK;
+    bool cl[2][2];
+    for (int iv = 0; iv < 2; ++iv) {
+        if (s->ncoef[iv] < 2 * s->order[iv]) return BSK_OK;           // the two ends must not overlap
+        if (!axis_is_uniform<T>(static_cast<const T *>(knots[iv]), s->order[iv], s->ncoef[iv], cl[iv][0], cl[iv][1])) return BSK_OK;
+    }
+    const int O = s->order[0];
+    // Unclamping multiplies the boundary control points by up to 6 (order 4) per variable and the corner
+    // cells' rounding errors with them (13^2 ulp): harmless in fp64, not in fp32 (order 2 changes nothing).
+    if (sizeof(T) == 4 && O > 2) return BSK_OK;
+    std::vector<long double> M;
+    if (!unclamp_matrix(O, M)) return BSK_OK;
+    const int nc0 = s->ncoef[0], nc1 = s->ncoef[1], nDep = s->nDep;
+    std::vector<long double> w((size_t)nDep * nc0 * nc1);
+    const T *src = static_cast<const T *>(coefs);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = src[i];
+    if (cl[0][0]) unclamp_axis(w, (size_t)nDep, nc0, (size_t)nc1, O, M, true);
+    if (cl[0][1]) unclamp_axis(w, (size_t)nDep, nc0, (size_t)nc1, O, M, false);
+    if (cl[1][0]) unclamp_axis(w, (size_t)nDep * nc0, nc1, 1, O, M, true);
+    if (cl[1][1]) unclamp_axis(w, (size_t)nDep * nc0, nc1, 1, O, M, false);
+
+    UniDesc<T> &ud = uni_of<T>(s);
+    memset(&ud, 0, sizeof(ud));
+    const bool cp_major = nDep <= 3;                              // [i0][i1][dep] (see bsk_uniform.hpp)
+    const int rs = uni_row_stride(nc1, nDep, O);
+    ud.rs = rs;
+    unsigned off = 0;
+    int nsmax = 1;
+    for (int iv = 0; iv < 2; ++iv) {
+        const T *k = static_cast<const T *>(knots[iv]);
+        ud.ns[iv] = s->ncoef[iv] - s->order[iv] + 1;
+        ud.ncoef[iv] = s->ncoef[iv];
+        ud.lo[iv] = k[s->order[iv] - 1];
+        ud.hi[iv] = k[s->ncoef[iv]];
+        ud.inv_h[iv] = T((long double)ud.ns[iv] / ((long double)ud.hi[iv] - (long double)ud.lo[iv]));
+        ud.kn_off[iv] = off;
+        off += (unsigned)((ud.ns[iv] + 1) * sizeof(T));
+        nsmax = std::max(nsmax, ud.ns[iv]);
+    }
+    ud.nDep = nDep;
+    // bias of the span estimate: above the rounding of (u - lo) * inv_h (2 ulp of a value < ns), far below 1
+    ud.eps = T(std::max<long double>(sizeof(T) == 8 ? 0x1p-30L : 0x1p-12L, 16.0L * nsmax * std::numeric_limits<T>::epsilon()));
+    off = (off + 15u) & ~15u;
+    ud.coef_off = off;
+    off += (unsigned)((cp_major ? (size_t)nc0 * rs : (size_t)nDep * nc0 * rs) * sizeof(T));
+    off = (off + 15u) & ~15u;
+    ud.img_bytes = off;
+    if ((size_t)off + TILE * sizeof(unsigned) > s->lds_max) return BSK_OK;
+    std::vector<unsigned char> img(off, 0);
+    for (int iv = 0; iv < 2; ++iv) {
+        const T *k = static_cast<const T *>(knots[iv]);
+        memcpy(img.data() + ud.kn_off[iv], k + s->order[iv] - 1, (size_t)(ud.ns[iv] + 1) * sizeof(T));
+    }
+    T *ic = reinterpret_cast<T *>(img.data() + ud.coef_off);
+    for (int dep = 0; dep < nDep; ++dep)
+        for (int i0 = 0; i0 < nc0; ++i0)
+            for (int i1 = 0; i1 < nc1; ++i1) {
+                const T v = T(w[((size_t)dep * nc0 + i0) * nc1 + i1]);
+                if (cp_major) ic[(size_t)i0 * rs + (size_t)i1 * nDep + dep] = v;              // [i0][i1][dep]
+                else ic[((size_t)dep * nc0 + i0) * rs + i1] = v;                               // [dep][i0][i1]
+            }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(s->uni_img.reserve(off));
+    HIPCHK(hipMemcpy(s->uni_img.p, img.data(), off, hipMemcpyHostToDevice));
+    s->uni = true;
+    return BSK_OK;
+}
+
 template <typename T, bool NORMAL>
 static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long long n, T *out, int normalize, int negate,
                                     hipStream_t st)
@@ -464,8 +652,40 @@ static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long lon
     const T *tab = static_cast<const T *>(s->tab);
     const T *coef = static_cast<const T *>(s->coef);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));
+    if (s->uni) {
+        // equally spaced knots: table-free front end on the unclamped image (bsk_uniform.hpp)
+        const UniDesc<T> &ud = uni_of<T>(s);
+        const size_t lds_u = (size_t)ud.img_bytes + TILE * sizeof(unsigned);
+        const int per_cu_u = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_u));
+#define BSK_JUNI(O_, ND_)                                                                                               \
+    do {                                                                                                                 \
+        s->last_kernel = "jac_uni";                                        \
+        HIPCHK(allow_lds(jac_uni<T, O_, NORMAL, ND_>, lds_u));                                                          \
+        hipLaunchKernelGGL((jac_uni<T, O_, NORMAL, ND_>), dim3(g), dim3(TILE), lds_u, st, ud, s->uni_img.p, cp,         \
+                           (unsigned)m, n0, out + n0, n, s->bad, normalize, negate);                                    \
+    } while (0)
+        const int ndu = (NORMAL || s->nDep > 3) ? 0 : s->nDep;
+        const long long cmaxu = rr_chunk_points();
+        for (long long n0 = 0; n0 < n; n0 += cmaxu) {
+            const long long m = std::min<long long>(n - n0, cmaxu);
+            const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu_u));
+            Params<T> cp = prm;
+            for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
+            if (s->order[0] == 4) {
+                if constexpr (NORMAL) BSK_JUNI(4, 3);
+                else switch (ndu) { case 1: BSK_JUNI(4, 1); break; case 2: BSK_JUNI(4, 2); break; case 3: BSK_JUNI(4, 3); break; default: BSK_JUNI(4, 0); }
+            } else {
+                if constexpr (NORMAL) BSK_JUNI(2, 3);
+                else switch (ndu) { case 1: BSK_JUNI(2, 1); break; case 2: BSK_JUNI(2, 2); break; case 3: BSK_JUNI(2, 3); break; default: BSK_JUNI(2, 0); }
+            }
+            HIPCHK(hipGetLastError());
+        }
+#undef BSK_JUNI
+        return BSK_OK;
+    }
 #define BSK_JROT(O_, ND_)                                                                                               \
     do {                                                                                                                 \
+        s->last_kernel = "jac_rowrot";                                        \
         HIPCHK(allow_lds(jac_rowrot<T, O_, NORMAL, ND_>, lds_rr));                                                      \
         hipLaunchKernelGGL((jac_rowrot<T, O_, NORMAL, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, tab, s->lut, coef, \
                            cp, (unsigned)m, n0, out + n0, n, s->bad, normalize, negate);                                \
@@ -506,11 +726,44 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
     if constexpr (NIND == 2 && (O == 2 || O == 4)) {
         // surfaces of order 2 / 4: row rotation on an odd-stride LDS image
         if (rowrot_applies<T>(s)) {
+            if (s->uni) {
+                // equally spaced knots: table-free front end on the unclamped image (bsk_uniform.hpp)
+                const UniDesc<T> &ud = uni_of<T>(s);
+                const size_t lds_u = (size_t)ud.img_bytes + TILE * sizeof(unsigned);
+                const int per_cu_u = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_u));
+#define BSK_UNI(DERIV_, ND_)                                                                                             \
+    do {                                                                                                                 \
+        s->last_kernel = "eval_uni";                                        \
+        HIPCHK(allow_lds(eval_uni<T, O, DERIV_, ND_>, lds_u));                                                          \
+        hipLaunchKernelGGL((eval_uni<T, O, DERIV_, ND_>), dim3(g), dim3(TILE), lds_u, st, ud, s->uni_img.p, cp,         \
+                           (unsigned)m, n0, out + n0, ostride, w, s->bad);                                              \
+    } while (0)
+#define BSK_UNI_ND(DERIV_)                                                                                               \
+    switch (s->nDep) {                                                                                                   \
+    case 1: BSK_UNI(DERIV_, 1); break;                                                                                   \
+    case 2: BSK_UNI(DERIV_, 2); break;                                                                                   \
+    case 3: BSK_UNI(DERIV_, 3); break;                                                                                   \
+    default: BSK_UNI(DERIV_, 0); break;                                                                                  \
+    }
+                const long long cmaxu = rr_chunk_points();
+                for (long long n0 = 0; n0 < n; n0 += cmaxu) {
+                    const long long m = std::min<long long>(n - n0, cmaxu);
+                    const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu_u));
+                    Params<T> cp = prm;
+                    for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
+                    if (deriv) { BSK_UNI_ND(true); } else { BSK_UNI_ND(false); }
+                    HIPCHK(hipGetLastError());
+                }
+#undef BSK_UNI_ND
+#undef BSK_UNI
+                return BSK_OK;
+            }
             const size_t lds_rr = rowrot_lds_bytes<T>(s);
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));
             // the number of dependent variables is a template constant up to 3 (0 = run-time loop)
 #define BSK_ROWROT(DERIV_, ND_)                                                                                          \
     do {                                                                                                                 \
+        s->last_kernel = "eval_rowrot";                                        \
         HIPCHK(allow_lds(eval_rowrot<T, O, DERIV_, ND_>, lds_rr));                                                      \
         hipLaunchKernelGGL((eval_rowrot<T, O, DERIV_, ND_>), dim3(g), dim3(TILE), lds_rr, st, d, td, tab, s->lut, coef, \
                            cp, (unsigned)m, n0, out + n0, ostride, w, s->bad);                                          \
@@ -541,10 +794,12 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     if (deriv) {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, true>, lds));
+        s->last_kernel = "eval_stream";
         hipLaunchKernelGGL((eval_stream<T, NIND, O, true>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     } else {
         HIPCHK(allow_lds(eval_stream<T, NIND, O, false>, lds));
+        s->last_kernel = "eval_stream";
         hipLaunchKernelGGL((eval_stream<T, NIND, O, false>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, tab, s->lut, coef, prm,
                            n, out, ostride, w, s->bad);
     }
@@ -585,6 +840,7 @@ static bsk_status launch_jac_stream(bsk_spline s, size_t lds, const Params<T> &p
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     HIPCHK(allow_lds(jac_stream<T, NIND, O>, lds));
+    s->last_kernel = "jac_stream";
     hipLaunchKernelGGL((jac_stream<T, NIND, O>), dim3(grid), dim3(STREAM_BLOCK), lds, st, d, td, static_cast<const T *>(s->tab),
                        s->lut, static_cast<const T *>(s->coef), prm, n, out, s->bad);
     HIPCHK(hipGetLastError());
@@ -724,6 +980,7 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
             const T *coef = static_cast<const T *>(s->coef);
 #define JMIX(NIND, OM)                                                                                              \
     case OM:                                                                                                        \
+        s->last_kernel = "jac_mixed";                                        \
         HIPCHK(allow_lds(jac_mixed<T, NIND, OM>, p.lds_bytes));                                                     \
         hipLaunchKernelGGL((jac_mixed<T, NIND, OM>), dim3(p.grid), dim3(p.block), p.lds_bytes, st, d, tab, coef, prm, n, \
                            out, s->bad);                                                                            \
@@ -1338,10 +1595,12 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
                 for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + c0;
                 if (s->order[0] == 4) {
                     HIPCHK(allow_lds(curv_rowrot<T, 4>, lds_rr));
+                    s->last_kernel = "curv_rowrot";
                     hipLaunchKernelGGL((curv_rowrot<T, 4>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, static_cast<const T *>(s->tab),
                                        s->lut, static_cast<const T *>(s->coef), cp, (unsigned)mm, c0, o + c0, s->bad);
                 } else {
                     HIPCHK(allow_lds(curv_rowrot<T, 2>, lds_rr));
+                    s->last_kernel = "curv_rowrot";
                     hipLaunchKernelGGL((curv_rowrot<T, 2>), dim3(g), dim3(TILE), lds_rr, st, d, tdr, static_cast<const T *>(s->tab),
                                        s->lut, static_cast<const T *>(s->coef), cp, (unsigned)mm, c0, o + c0, s->bad);
                 }
@@ -1764,6 +2023,8 @@ extern "C" bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void
 // Streams u, v -> out (3 rows) with the evaluation kernels' launch geometry; mode 0/1 = 8/16
 // bytes per lane, blocks_per_cu workgroups per CU, lds_bytes of dynamic LDS each.  Device
 // pointers, fp64.  Used by tools/ to measure the memory-side floor; not an evaluation call.
+extern "C" const char *bsk_last_kernel(bsk_spline s) { return s ? s->last_kernel : ""; }
+
 extern "C" bsk_status bsk_debug_probe(bsk_spline s, int mode, int blocks_per_cu, int threads, int64_t lds_bytes,
                                       const void *u, const void *v, int64_t n, void *out, void *stream)
 {

@@ -21,6 +21,7 @@ static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long lo
 #define GATHER_ND(ND)                                                                                             \
     case ND:                                                                                                      \
         HIPCHK(allow_lds(eval_gather<T, NIND, O, ND, MIXED>, lds));                                               \
+        s->last_kernel = "eval_gather";                                                                           \
         hipLaunchKernelGGL((eval_gather<T, NIND, O, ND, MIXED>), dim3(grid), dim3(block), lds, st, d, tab, aos, prm, n,  \
                            out, ostride, w, s->bad);                                                              \
         break;
@@ -99,6 +100,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
+        s->last_kernel = "cell-order pipeline (eval_binned_lds)";                                                        \
         hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(BIN_BLOCK), lds_count, st, d, bp, tab, prm, n, \
                            cell, M, s->bad);                                                                             \
         hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \

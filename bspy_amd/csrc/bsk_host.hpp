@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -83,6 +84,12 @@ struct bsk_spline_s {
     void *pin = nullptr;                // pinned, device-mapped host buffer of the small-call path (run_small)
     size_t pin_cap = 0;
     struct HostPipe *pipe = nullptr;    // pinned staging, streams, events of the large BSK_HOST path (bsk_api.hip)
+    // uniform-knot surface path (bsk_uniform.hpp): prebuilt LDS image (domain knots + unclamped coefficients)
+    bool uni = false;
+    UniDesc<float> u32;
+    UniDesc<double> u64;
+    DevBuf uni_img;
+    const char *last_kernel = "";       // family of the most recent point-kernel launch (bsk_last_kernel)
 };
 
 template <typename T>
@@ -91,6 +98,12 @@ template <>
 inline Desc<float> &desc_of<float>(bsk_spline s) { return s->d32; }
 template <>
 inline Desc<double> &desc_of<double>(bsk_spline s) { return s->d64; }
+template <typename T>
+UniDesc<T> &uni_of(bsk_spline s);
+template <>
+inline UniDesc<float> &uni_of<float>(bsk_spline s) { return s->u32; }
+template <>
+inline UniDesc<double> &uni_of<double>(bsk_spline s) { return s->u64; }
 template <typename T>
 TileDesc<T> &tile_of(bsk_spline s);
 template <>

@@ -129,4 +129,19 @@ struct TileDesc {
     unsigned tab_bytes, lut_bytes, coef_bytes;   // rounded up to 16
 };
 
+// Descriptor of the uniform-knot surface kernels (bsk_uniform.hpp): domain, span width, image layout.
+template <typename T>
+struct UniDesc {
+    T lo[2], hi[2];        // domain
+    T inv_h[2];            // spans per unit parameter
+    T eps;                 // bias of the span estimate (see uni_spans2)
+    int ns[2];             // spans per variable
+    int ncoef[2];
+    int nDep;
+    int rs;                // row stride of the coefficient image (elements), = 32 / order (mod 32)
+    unsigned kn_off[2];    // byte offsets inside the image
+    unsigned coef_off;
+    unsigned img_bytes;    // multiple of 16
+};
+
 }  // namespace bsk

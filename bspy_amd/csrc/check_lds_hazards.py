@@ -18,7 +18,7 @@ usage: check_lds_hazards.py <device .s> [--allow-none] [kernel-name-substring ..
 import re
 import sys
 
-KERNELS = ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot")
+KERNELS = ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni")
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 WAIT = re.compile(r"lgkmcnt\((\d+)\)")
 

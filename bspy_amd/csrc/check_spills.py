@@ -8,7 +8,7 @@ log = open(sys.argv[1]).read()
 bad = []
 for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", log, re.S):
     name, scratch = m.group(1), int(m.group(2))
-    if (any(k in name for k in ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot"))) and scratch:
+    if (any(k in name for k in ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni"))) and scratch:
         bad.append((name, scratch))
 if bad:
     for name, scratch in bad:

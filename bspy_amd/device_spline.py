@@ -94,6 +94,10 @@ class DeviceSpline:
     def close(self):
         self._finalizer()
 
+    def last_kernel(self):
+        """Family name of the kernel the most recent point call on this object launched (diagnostic)."""
+        return nv.lib().bsk_last_kernel(self._handle).decode()
+
     # ------------------------------------------------------------------ host (NumPy) calls
     def _host_params(self, points):
         if len(points) != self.nInd:

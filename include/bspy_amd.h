@@ -171,6 +171,20 @@ bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void *knots, in
                               const void *u, int64_t n, int derivative_order, int taylor_coefs,
                               const int32_t *knot_in, int32_t *ix_out, void *basis_out);
 
+/*
+ * Diagnostics (no reference counterpart; used by bench.py, tools/ and the tests).
+ *   bsk_last_kernel : family name of the kernel the most recent point call on this handle launched
+ *                     ("eval_uni", "eval_rowrot", "eval_stream", "cell-order pipeline (...)", ...), so
+ *                     that measurements and tests name the kernel that actually ran.
+ *   bsk_debug_probe : memory-side floor of the LDS-resident kernels' launch geometry: streams two fp64
+ *                     parameter arrays in and three result arrays out with trivial arithmetic
+ *                     (mode 0: 8 B per lane per access, mode 1: 16 B), `blocks_per_cu` workgroups of
+ *                     `threads` lanes per CU with `lds_bytes` of LDS allocated.  tools/probe_stream.py.
+ */
+const char *bsk_last_kernel(bsk_spline s);
+bsk_status bsk_debug_probe(bsk_spline s, int mode, int blocks_per_cu, int threads, int64_t lds_bytes,
+                           const void *u, const void *v, int64_t n, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
