@@ -15,7 +15,7 @@ There is no CPU compute path: without the shared library every call raises.
 """
 from . import _native
 from ._native import BskError, DomainError, NativeLibraryError
-from .device_spline import DeviceSpline, bspline_values_batch, get_device, set_device
+from .device_spline import DeviceSpline, MultiDeviceSpline, bspline_values_batch, get_device, set_device
 from .device_spline import tessellate as tessellate_tables
 from .spline import Spline
 from .collocation import collocation_matrix
@@ -36,6 +36,6 @@ def tessellate(splines, u, v, normals=True, normalize=True):
     tables = [_se.device_tables(s, dev) for s in splines]
     return tessellate_tables(tables, (u, v), normals=normals, normalize=normalize, negate=neg.pop() if neg else False)
 
-__all__ = ["Spline", "SplineBlock", "DeviceSpline", "tessellate", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
+__all__ = ["Spline", "SplineBlock", "DeviceSpline", "MultiDeviceSpline", "tessellate", "collocation_matrix", "bspline_values_batch", "set_device", "get_device",
            "BskError", "DomainError", "NativeLibraryError"]
 __version__ = "0.1.0"

@@ -25,6 +25,8 @@ SYMBOLS = (
     "bsk_spline_create", "bsk_spline_update", "bsk_spline_destroy",
     "bsk_evaluate", "bsk_jacobian", "bsk_normal", "bsk_curvature", "bsk_evaluate_grid", "bsk_tessellate",
     "bsk_domain_status", "bsk_bspline_values", "bsk_last_kernel", "bsk_debug_probe",
+    "bsk_multi_create", "bsk_multi_destroy", "bsk_multi_shard_plan", "bsk_multi_stream", "bsk_multi_evaluate",
+    "bsk_multi_jacobian",
 )
 
 
@@ -96,6 +98,13 @@ def lib():
     L.bsk_domain_status.argtypes = [_vp, _vp, _i64p]
     L.bsk_bspline_values.argtypes = [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _i64,
                                      ctypes.c_int, ctypes.c_int, _i32p, _i32p, _vp]
+    L.bsk_multi_create.argtypes = [ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, _ip, _ip, _vpp, _vp,
+                                   ctypes.POINTER(_vp)]
+    L.bsk_multi_destroy.argtypes = [_vp]
+    L.bsk_multi_shard_plan.argtypes = [_vp, _i64, _i64p]
+    L.bsk_multi_stream.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(_vp)]
+    L.bsk_multi_evaluate.argtypes = [_vp, _ip, _vpp, _i64, ctypes.c_int, _vpp, ctypes.c_int, _i64p]
+    L.bsk_multi_jacobian.argtypes = [_vp, _vpp, _i64, ctypes.c_int, _vpp, ctypes.c_int, _i64p]
     L.bsk_last_kernel.argtypes = [_vp]
     L.bsk_last_kernel.restype = ctypes.c_char_p
     L.bsk_debug_probe.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, _vp, _vp, _i64, _vp, _vp]

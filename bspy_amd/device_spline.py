@@ -384,3 +384,91 @@ def bspline_values_batch(knots, order, u, derivative_order=0, taylor_coefs=False
                                      ix.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), basis.ctypes.data)
     nv.check(st)
     return ix, basis
+
+
+class MultiDeviceSpline:
+    """One spline replicated on several GPUs of a node, driven from ONE process through the
+    ``bsk_multi_*`` entry points (include/bspy_amd.h): the batch is cut into contiguous shards of
+    ``ceil(N / ndev)`` points, every device evaluates its shard, and results are exchanged only on
+    request (one grouped RCCL all-gather).  The one-process-per-GPU form is ``bspy_amd.sharding``."""
+
+    def __init__(self, order, nCoef, knots, coefs, dtype=np.float64, devices=None):
+        self.dtype = np.dtype(dtype)
+        self.order = tuple(int(o) for o in order)
+        self.nCoef = tuple(int(c) for c in nCoef)
+        self.nInd = len(self.order)
+        coefs = np.ascontiguousarray(coefs, self.dtype)
+        self.nDep = int(coefs.shape[0])
+        ks = [np.ascontiguousarray(k, self.dtype) for k in knots]
+        self.devices = list(range(nv.device_count())) if devices is None else [int(d) for d in devices]
+        handle = ctypes.c_void_p()
+        st = nv.lib().bsk_multi_create(nv.dtype_code(self.dtype), len(self.devices), nv.int_array(self.devices), self.nInd,
+                                       self.nDep, nv.int_array(self.order), nv.int_array(self.nCoef),
+                                       nv.ptr_array([k.ctypes.data for k in ks]), coefs.ctypes.data, ctypes.byref(handle))
+        nv.check(st)
+        self._handle = handle
+        self._finalizer = weakref.finalize(self, lambda h: nv.lib().bsk_multi_destroy(h), handle)
+
+    def close(self):
+        self._finalizer()
+
+    def shard_plan(self, n):
+        start = (ctypes.c_int64 * (len(self.devices) + 1))()
+        nv.check(nv.lib().bsk_multi_shard_plan(self._handle, int(n), start))
+        return list(start)
+
+    def _host(self, jac, points, wrt):
+        if len(points) != self.nInd:
+            raise ValueError(f"Incorrect number of parameter values: {len(points)}")
+        ps = [np.ascontiguousarray(p, self.dtype).ravel() for p in points]
+        n = ps[0].size
+        rows = self.nDep * self.nInd if jac else self.nDep
+        out = np.empty((rows, n), self.dtype)
+        bad = ctypes.c_int64(-1)
+        outs = nv.ptr_array([out.ctypes.data])
+        if jac:
+            st = nv.lib().bsk_multi_jacobian(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST, outs, 0,
+                                             ctypes.byref(bad))
+        else:
+            st = nv.lib().bsk_multi_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None,
+                                             nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST, outs, 0, ctypes.byref(bad))
+        nv.check(st, bad)
+        return out.reshape(self.nDep, self.nInd, n) if jac else out
+
+    def evaluate(self, points, wrt=None):
+        """Host arrays in, host (nDep, N) out; every device moves its shard over its own PCIe link."""
+        return self._host(False, points, wrt)
+
+    def jacobian(self, points):
+        return self._host(True, points, None)
+
+    def evaluate_device(self, shards, n, wrt=None, gather=False, jacobian=False):
+        """``shards[d]`` = the nInd CUDA tensors of device slot d's shard (on that device), ``n`` the
+        global point count.  Returns one tensor per device: the compact ``(rows, shard)`` block, or with
+        ``gather`` the whole ``(rows, ndev * ceil(n / ndev))`` result on every device (columns >= n are
+        padding)."""
+        import torch
+        ndev = len(self.devices)
+        plan = self.shard_plan(n)
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        rows = self.nDep * self.nInd if jacobian else self.nDep
+        chunk = -(-int(n) // ndev) if n > 0 else 0
+        flat, outs = [], []
+        for d in range(ndev):
+            cnt = plan[d + 1] - plan[d]
+            for t in shards[d]:
+                if t.numel() != cnt or t.dtype != tdt or not t.is_contiguous() or t.device.index != self.devices[d]:
+                    raise ValueError(f"shard {d}: need {cnt} contiguous {tdt} values on device {self.devices[d]}")
+                flat.append(t.data_ptr())
+            outs.append(torch.empty((rows, ndev * chunk if gather else cnt), dtype=tdt, device=torch.device("cuda", self.devices[d])))
+        torch.cuda.synchronize()              # the library's streams are not torch's
+        bad = ctypes.c_int64(-1)
+        optrs = nv.ptr_array([o.data_ptr() for o in outs])
+        if jacobian:
+            st = nv.lib().bsk_multi_jacobian(self._handle, nv.ptr_array(flat), int(n), nv.BSK_DEVICE, optrs, 1 if gather else 0,
+                                             ctypes.byref(bad))
+        else:
+            st = nv.lib().bsk_multi_evaluate(self._handle, nv.int_array(wrt) if wrt is not None else None, nv.ptr_array(flat),
+                                             int(n), nv.BSK_DEVICE, optrs, 1 if gather else 0, ctypes.byref(bad))
+        nv.check(st, bad)
+        return outs

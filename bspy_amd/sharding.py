@@ -6,9 +6,8 @@ caller asks for the full result everywhere - the shards are all-gathered.
 
 The reference has no distributed code at all; points are independent, so the
 path shards with NO data-path collective.  ``gather=True`` adds the one exchange step
-BASELINE.json names (all-gather of results): one ``all_gather_into_tensor`` per dependent
-variable, each rank contributing ``ceil(N / world)`` values, written straight into the
-final SoA layout.  Over 7 xGMI links (~153 GB/s each) that gather costs several times the
+BASELINE.json names (all-gather of results): ONE ``all_gather_into_tensor`` of every rank's
+``(rows, ceil(N / world))`` block followed by one device copy into the ``(rows, N)`` SoA layout.  Over 7 xGMI links (~153 GB/s each) that gather costs several times the
 kernel, so leave results sharded (``gather=False``) when the consumer is
 sharded too.
 """
@@ -32,12 +31,13 @@ class ShardedEvaluator:
 
     ``spline``      a ``bspy_amd.Spline`` (or anything with its attributes)
     ``group``       torch.distributed process group (default: WORLD)
+    ``collectives_at_world1``  run the collectives in a one-rank group too (tests)
     ``local_eval``  optional ``f(op, points, wrt) -> array (rows, m)`` replacing the local
                     GPU evaluation (tests inject a CPU checker under gloo); ``op`` is
                     "evaluate" or "jacobian".  Default: this rank's DeviceSpline.
     """
 
-    def __init__(self, spline, group=None, local_eval=None, device=None):
+    def __init__(self, spline, group=None, local_eval=None, device=None, collectives_at_world1=False):
         import torch.distributed as dist
         self.dist = dist
         self.spline = spline
@@ -46,6 +46,8 @@ class ShardedEvaluator:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_eval = local_eval
         self.device = device
+        # run the all-reduce / all-gather even in a one-rank group (exercises the RCCL path on one GPU)
+        self.coll = dist.is_initialized() and (self.world > 1 or bool(collectives_at_world1))
 
     # -- local compute -------------------------------------------------------------------
     def _local(self, op, pts, wrt):
@@ -71,21 +73,23 @@ class ShardedEvaluator:
         return res, -1
 
     # -- public API ----------------------------------------------------------------------
-    def evaluate(self, points, wrt=None, gather=True, sharded_input=False, total=None):
-        return self._run("evaluate", points, wrt, gather, sharded_input, total)
+    def evaluate(self, points, wrt=None, gather=True, sharded_input=False, total=None, check=True):
+        return self._run("evaluate", points, wrt, gather, sharded_input, total, check)
 
-    def derivative(self, with_respect_to, points, gather=True, sharded_input=False, total=None):
-        return self._run("evaluate", points, [int(w) for w in with_respect_to], gather, sharded_input, total)
+    def derivative(self, with_respect_to, points, gather=True, sharded_input=False, total=None, check=True):
+        return self._run("evaluate", points, [int(w) for w in with_respect_to], gather, sharded_input, total, check)
 
-    def jacobian(self, points, gather=True, sharded_input=False, total=None):
-        return self._run("jacobian", points, None, gather, sharded_input, total)
+    def jacobian(self, points, gather=True, sharded_input=False, total=None, check=True):
+        return self._run("jacobian", points, None, gather, sharded_input, total, check)
 
-    def _run(self, op, points, wrt, gather, sharded_input, total):
+    def _run(self, op, points, wrt, gather, sharded_input, total, check=True):
         """points: nInd 1-D arrays/tensors.  With ``sharded_input`` each rank passes only its
         own shard (``total`` = global point count, shards as ``shard_bounds``); otherwise
         every rank passes the full batch and takes its slice.
         Returns (rows, N) if gather else this rank's (rows, n_local); rows = nDep
-        (evaluate/derivative) or nDep * nInd (jacobian, row = d * nInd + j)."""
+        (evaluate/derivative) or nDep * nInd (jacobian, row = d * nInd + j).
+        ``check=False`` skips the blocking agreement on the first out-of-domain point (a MIN
+        all-reduce + host read per call); a local offender still raises on its own rank."""
         import torch
         nind = self.spline.nInd
         if len(points) != nind:
@@ -104,36 +108,47 @@ class ShardedEvaluator:
             local = [p[start:stop] for p in points]
         res, bad_local = self._local(op, local, wrt)
 
-        # the reference raises for the first offending point; make every rank agree on it
-        import_max = np.iinfo(np.int64).max
-        bad = torch.tensor([start + bad_local if bad_local >= 0 else import_max], dtype=torch.int64)
+        # Collectives run where the backend needs them: RCCL ("nccl") only moves device memory, so NumPy
+        # results / the offender index are staged on this rank's GPU; gloo takes them as they are.
         is_t = hasattr(res, "is_cuda") or (res is None and hasattr(local[0], "is_cuda"))
-        dev = local[0].device if hasattr(local[0], "is_cuda") else None
-        if self.world > 1:
-            if dev is not None and dev.type == "cuda":
-                bad = bad.to(dev)
+        cdev = None
+        if self.coll and self.dist.get_backend(self.group) == "nccl":
+            if is_t and hasattr(local[0], "is_cuda"):
+                cdev = local[0].device
+            else:
+                from .device_spline import get_device
+                cdev = torch.device("cuda", get_device() if self.device is None else int(self.device))
+
+        # the reference raises for the first offending point; make every rank agree on it
+        # (one MIN all-reduce; ``check=False`` skips it - the kernels' own record stays queryable)
+        import_max = np.iinfo(np.int64).max
+        bad_here = start + bad_local if bad_local >= 0 else import_max
+        if self.coll and check:
+            bad = torch.tensor([bad_here], dtype=torch.int64, device=cdev)
             self.dist.all_reduce(bad, op=self.dist.ReduceOp.MIN, group=self.group)
-        if int(bad.item()) != import_max:
-            idx = int(bad.item())
+            bad_here = int(bad.item())
+        if bad_here != import_max:
             where = ""
             if not sharded_input:
-                pt = [float(p[idx]) for p in points]
+                pt = [float(p[bad_here]) for p in points]
                 where = f" {np.atleast_1d(pt)}"
-            raise ValueError(f"Spline evaluation outside domain:{where} (flat index {idx})")
-        if not gather or self.world == 1:
+            raise ValueError(f"Spline evaluation outside domain:{where} (flat index {bad_here})")
+        if not gather or not self.coll:
             return res
 
-        # all-gather: one collective per output row, written in place into the (rows, N) result
+        # all-gather: ONE collective into (world, rows, chunk), then one device copy into the (rows, N) layout
         chunk = shard_chunk(n, self.world)
         rows = res.shape[0]
         t = res if is_t else torch.from_numpy(np.ascontiguousarray(res))
-        full = torch.empty((rows, self.world * chunk), dtype=t.dtype, device=t.device)
+        if cdev is not None and t.device != cdev:
+            t = t.to(cdev)
         if t.shape[1] != chunk:          # short tail shard: pad to the common chunk
             pad = torch.zeros((rows, chunk), dtype=t.dtype, device=t.device)
             pad[:, :t.shape[1]] = t
             t = pad
-        t = t.contiguous()
-        for r in range(rows):
-            self.dist.all_gather_into_tensor(full[r], t[r], group=self.group)
-        full = full[:, :n]
-        return full if is_t else full.numpy()
+        gathered = torch.empty((self.world * rows, chunk), dtype=t.dtype, device=t.device)   # rank-major concatenation
+        self.dist.all_gather_into_tensor(gathered, t.contiguous(), group=self.group)
+        full = gathered.view(self.world, rows, chunk).permute(1, 0, 2).reshape(rows, self.world * chunk)[:, :n]
+        if is_t:
+            return full
+        return full.cpu().numpy() if full.device.type != "cpu" else full.numpy()

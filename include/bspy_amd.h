@@ -172,6 +172,36 @@ bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void *knots, in
                               const int32_t *knot_in, int32_t *ix_out, void *basis_out);
 
 /*
+ * Multi-device evaluation in ONE process (north_star: "sharding the evaluation-point batch with an RCCL
+ * all-gather of results"; the reference has no multi-device code).  A bsk_multi holds one
+ * replica of the spline tables and one stream per device.  A call cuts the n points into contiguous shards
+ * of ceil(n / ndev) points (bsk_multi_shard_plan: start[d] .. start[d + 1]), evaluates every shard on its
+ * device through bsk_evaluate / bsk_jacobian, and exchanges results only on request:
+ *   mem == BSK_HOST    uvw[iv] = n host values; out[0] = host (rows, n); every device copies its shard over
+ *                      its own PCIe link; `gather` is ignored (the host holds the whole result).
+ *   mem == BSK_DEVICE  uvw[d * nInd + iv] = device d's shard of variable iv (on device d);
+ *     gather == 0      out[d] = device d's compact (rows, shard) block: no collective at all.
+ *     gather != 0      out[d] = (rows, ndev * chunk) on device d, chunk = ceil(n / ndev): every device
+ *                      receives every shard - one grouped RCCL exchange (ncclGroupStart, one ncclAllGather
+ *                      per device and row, ncclGroupEnd); columns >= n of the last chunk are padding.
+ *                      librccl.so is opened on first use; BSK_ERR_UNSUPPORTED when it cannot be loaded.
+ *   rows = nDep (evaluate / derivative) or nDep * nInd (jacobian).
+ *   first_bad = global index of the first out-of-domain point (BSK_ERR_DOMAIN), else -1.  The call returns
+ *   when every device has finished.
+ */
+typedef struct bsk_multi_s *bsk_multi;
+bsk_status bsk_multi_create(bsk_dtype dtype, int ndev, const int *devices /* NULL = 0 .. ndev-1 */, int nInd, int nDep,
+                            const int *order, const int *nCoef, const void *const *knots, const void *coefs,
+                            bsk_multi *out);
+bsk_status bsk_multi_destroy(bsk_multi m);
+bsk_status bsk_multi_shard_plan(bsk_multi m, int64_t n, int64_t *start /* ndev + 1 entries */);
+bsk_status bsk_multi_stream(bsk_multi m, int d, void **stream /* hipStream_t of device slot d */);
+bsk_status bsk_multi_evaluate(bsk_multi m, const int *wrt, const void *const *uvw, int64_t n, bsk_mem mem,
+                              void *const *out, int gather, int64_t *first_bad);
+bsk_status bsk_multi_jacobian(bsk_multi m, const void *const *uvw, int64_t n, bsk_mem mem, void *const *out,
+                              int gather, int64_t *first_bad);
+
+/*
  * Diagnostics (no reference counterpart; used by bench.py, tools/ and the tests).
  *   bsk_last_kernel : family name of the kernel the most recent point call on this handle launched
  *                     ("eval_uni", "eval_rowrot", "eval_stream", "cell-order pipeline (...)", ...), so
