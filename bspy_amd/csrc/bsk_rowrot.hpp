@@ -434,8 +434,9 @@ __global__ __launch_bounds__(TILE) void jac_rowrot(const Desc<T> d, const TileDe
             T nz = su[0] * sv[1] - sv[0] * su[1];
             if (negate) { nx = -nx; ny = -ny; nz = -nz; }
             if (normalize) {
-                const T len = sqrt(nx * nx + ny * ny + nz * nz);
-                nx = nx / len; ny = ny / len; nz = nz / len;
+                // one division: 1 / |n| times the components (a second rounding, 1 ulp, against three fp64 divisions)
+                const T inv = T(1) / sqrt(nx * nx + ny * ny + nz * nz);
+                nx = nx * inv; ny = ny * inv; nz = nz * inv;
             }
             rr_store(out, off, nx);
             rr_store(out + ostride, off, ny);
