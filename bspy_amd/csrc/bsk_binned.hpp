@@ -25,6 +25,7 @@
 // atomics of different waves) cannot change the output.
 #pragma once
 #include "bsk_gather.hpp"
+#include <type_traits>
 
 namespace bsk {
 
@@ -62,8 +63,14 @@ __device__ __forceinline__ int bin_cell(const T *stab, const Desc<T> &d, const B
 }
 
 // LDS: [axis tables][cells x u32]
+// Four independent points per lane and iteration (loads, span searches and histogram updates of the four
+// interleave: a single chain per lane is bound by its dependent LDS / HBM round trips).
+// (Carrying the span of the third variable from here to eval_cellsort in the records' spare word was
+// measured: the search costs this kernel 23 us and saves the evaluation 16 - not kept.)
+constexpr int BIN_ILP = 4;
+
 template <typename T, int NIND, int O>
-__global__ __launch_bounds__(BIN_BLOCK) void bin_count(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+__global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                        const Params<T> prm, const long long N,
                                                        unsigned short *__restrict__ cell, unsigned *__restrict__ M,
                                                        unsigned long long *bad)
@@ -75,18 +82,28 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_count(const Desc<T> d, const Bi
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
     const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
-    for (long long n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        bool outside = false;
-        T u[NIND];
+    for (long long n0 = lo + threadIdx.x; n0 < hi; n0 += (long long)blockDim.x * BIN_ILP) {
+        T u[BIN_ILP][NIND];
 #pragma unroll
-        for (int iv = 0; iv < NIND; ++iv) {
-            u[iv] = prm.p[iv][n];
-            outside |= (u[iv] < d.lo[iv]) | (u[iv] > d.hi[iv]);
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            const long long nn = n < hi ? n : hi - 1;
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) u[k][iv] = prm.p[iv][nn];
         }
-        if (outside) record_bad(bad, n);
-        const int c = bin_cell<T, O>(stab, d, bp, u[0], u[1]);
-        cell[n] = (unsigned short)c;
-        atomicAdd(&hist[c], 1u);
+#pragma unroll
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            if (n < hi) {
+                bool outside = false;
+#pragma unroll
+                for (int iv = 0; iv < NIND; ++iv) outside |= (u[k][iv] < d.lo[iv]) | (u[k][iv] > d.hi[iv]);
+                if (outside) record_bad(bad, n);
+                const int c = bin_cell<T, O>(stab, d, bp, u[k][0], u[k][1]);
+                cell[n] = (unsigned short)c;
+                atomicAdd(&hist[c], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) M[(size_t)i * bp.chunks + blockIdx.x] = hist[i];
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(1024) void bin_topscan(const int cells, const unsig
 }
 
 template <typename T, int NIND>
-__global__ __launch_bounds__(BIN_BLOCK) void bin_scatter(const BinPlan bp, const Params<T> prm, const long long N,
+__global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Params<T> prm, const long long N,
                                                          const unsigned short *__restrict__ cell,
                                                          const unsigned *__restrict__ M, const unsigned *__restrict__ start,
                                                          BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot)
@@ -147,15 +164,28 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_scatter(const BinPlan bp, const
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) next[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
     __syncthreads();
     const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
-    for (long long n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        const unsigned p = atomicAdd(&next[cell[n]], 1u);
-        BinRec<T, NIND> r;
+    for (long long n0 = lo + threadIdx.x; n0 < hi; n0 += (long long)blockDim.x * BIN_ILP) {
+        unsigned w[BIN_ILP];
+        BinRec<T, NIND> r[BIN_ILP];
 #pragma unroll
-        for (int k = 0; k < BinRec<T, NIND>::WORDS; ++k) r.v[k] = T(0);
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            const long long nn = n < hi ? n : hi - 1;
+            w[k] = cell[nn];
 #pragma unroll
-        for (int iv = 0; iv < NIND; ++iv) r.v[iv] = prm.p[iv][n];
-        rec[p] = r;
-        slot[n] = p;
+            for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            if (n < hi) {
+                const unsigned p = atomicAdd(&next[w[k]], 1u);
+                rec[p] = r[k];
+                slot[n] = p;
+            }
+        }
     }
 }
 
@@ -307,16 +337,255 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// eval_cellsort: three variables, cells grouped a second time INSIDE the evaluation workgroup.
+//
+// eval_binned_lds gathers every lane's own window from the LDS bundle: 2 KB of LDS reads per cfg5
+// point with ~2-way bank conflicts (lanes of a wave sit in different spans of the third variable).
+// Here a workgroup sorts each tile of 1024 records of a (span0, span1) bin by the span of the THIRD
+// variable in LDS (counting sort, segments padded to multiples of four lanes), so four consecutive
+// lanes always share one cell (span0, span1, span2) and neighbouring lanes mostly do.  The
+// contraction  r[dep] = sum_{ijk} b0_i b1_j b2_k C[i][j][k][dep]  of a 4-lane block then shares its
+// coefficient operand:
+//   MFMA = true   v_mfma_f32_4x4x1_16b_f32: sixteen 4 x 4 outer products per instruction - block b
+//                 accumulates D_b[dep][point] += C_b[step][dep] * w_point[step] over the O^3 window
+//                 steps.  Lane l = 4 b + j feeds the weight of ITS point (B operand) and the
+//                 coefficient of dependent variable j of ITS block's cell (A operand: one 4-byte LDS
+//                 read per step, bundle kept [row][dep][k]); it receives the four dependent variables
+//                 of its own point.  The multiply-adds leave the vector ALU (which forms the O^3
+//                 weights meanwhile): 500 B of LDS reads per point instead of 2 KB.
+//   MFMA = false  the same sorted lanes on the vector ALU: eval_gather's arithmetic, every control point
+//                 one 16-byte LDS read that the lanes of a cell share (broadcast, conflict free).
+// Results go to tmp[slot] of the record's ORIGINAL slot, so bin_unpermute is unchanged.  Summation
+// order differs from eval_gather (one chain over the window per accumulator): results agree to
+// rounding, not bitwise.   LDS: [axis tables][bundle][sorted records][histogram / segment starts]
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_TILE = 1024;           // records sorted at a time (4 per lane of a 256-lane workgroup)
+constexpr int CS_MAX_S2 = 256;          // spans of the third variable the LDS histogram holds
+
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int O, int ND, bool MFMA>
+__global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+                                                     const T *__restrict__ aos, const unsigned *__restrict__ start,
+                                                     const BinRec<T, 3> *__restrict__ rec, const long long N,
+                                                     BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
+{
+    static_assert(!MFMA || (sizeof(T) == 4 && ND <= 4), "the 4x4x1 fp32 MFMA form");
+    static_assert(sizeof(BinRec<T, 3>) == 4 * sizeof(T), "record = u, v, w, tag");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ncl = d.ncoef[2];
+    const int S2 = ncl - d.order[2] + 1;
+    constexpr int ROWS = O * O;
+    constexpr int DP = MFMA ? 4 : ND;                       // dependent-variable slots of a bundle row
+    const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
+    const size_t bun_b = (sizeof(T) * (size_t)ROWS * DP * ncl + 15) & ~(size_t)15;
+    T *stab = reinterpret_cast<T *>(smem);
+    T *bun = reinterpret_cast<T *>(smem + tab_b);
+    BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + tab_b + bun_b);
+    unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(CS_TILE + 4 * S2));
+    unsigned *segs = hist + CS_MAX_S2;                      // segment start of every span, then [CS_MAX_S2] = padded total
+    __shared__ int s_first;
+    for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+    const long long per = (N + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
+    if (threadIdx.x == 0) {
+        int a = 0, b = bp.cells - 1;
+        while (a < b) {
+            const int m = (a + b + 1) >> 1;
+            if ((long long)start[m] <= lo) a = m; else b = m - 1;
+        }
+        s_first = a;
+    }
+    __syncthreads();
+    const T *tab2 = stab + d.off[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cs0 = d.ncoef[1] * d.ncoef[2], cs1 = d.ncoef[2];   // table strides (control points)
+    for (int c = s_first; c < bp.cells && lo < hi; ++c) {
+        const long long cb = start[c], ce = c + 1 < bp.cells ? (long long)start[c + 1] : N;
+        if (cb >= hi) break;
+        const long long sl = cb > lo ? cb : lo, sh = ce < hi ? ce : hi;
+        if (sl >= sh) continue;
+        const int q0 = c / bp.n1, q1 = c % bp.n1;          // window starts of the first two variables (bins are exact spans)
+        __syncthreads();                                     // previous bin's readers are done
+        // bundle: row r = (i, j) of the bin's O x O control-point rows along the third variable
+        for (int r = wave; r < ROWS; r += 4) {
+            const int i = r / O, j = r - i * O;
+            const T *__restrict__ src = aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1) * ND;
+            if constexpr (MFMA) {
+                // [row][dep][k], dependent variables beyond ND zero
+                if constexpr (ND == 4) {
+                    for (int k = lane; k < ncl; k += 64) {
+                        const float4 q = *reinterpret_cast<const float4 *>(src + 4 * k);       // one control point
+                        T *dst = bun + (size_t)r * 4 * ncl + k;
+                        dst[0] = q.x; dst[ncl] = q.y; dst[2 * ncl] = q.z; dst[3 * ncl] = q.w;
+                    }
+                } else {
+                    for (int e = lane; e < 4 * ncl; e += 64) {
+                        const int dep = e / ncl, k = e - dep * ncl;
+                        bun[(size_t)r * 4 * ncl + e] = dep < ND ? src[k * ND + dep] : T(0);
+                    }
+                }
+            } else {
+                for (int e = lane; e < ncl * ND; e += 64) bun[(size_t)r * ncl * ND + e] = src[e];
+            }
+        }
+        using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+        // records of the first tile of this bin; every later tile is fetched while its predecessor is evaluated
+        BinRec<T, 3> rc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long p = sl + i * 256 + (long long)threadIdx.x;
+            rc[i] = rec[p < sh ? p : sh - 1];
+        }
+        for (long long t0 = sl; t0 < sh; t0 += CS_TILE) {
+            const int cnt = (int)((sh - t0) < CS_TILE ? (sh - t0) : CS_TILE);
+            __syncthreads();                                 // bundle staged / previous tile's readers are done
+            for (int k = threadIdx.x; k < S2; k += blockDim.x) hist[k] = 0u;
+            __syncthreads();
+            // --- span of the third variable, rank inside it
+            int key[4];
+            unsigned rank[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 256 + (int)threadIdx.x;
+                key[i] = -1;
+                if (idx < cnt) {
+                    key[i] = find_span<T>(tab2, d.order[2], ncl, d.steps[2], rc[i].v[2]) - d.order[2];
+                    rank[i] = atomicAdd(&hist[key[i]], 1u);
+                }
+            }
+            __syncthreads();
+            // --- segment starts: exclusive scan of the counts rounded up to multiples of four (one wave)
+            if (wave == 0) {
+                unsigned carry = 0;
+                for (int k0 = 0; k0 < S2; k0 += 64) {
+                    const int k = k0 + lane;
+                    const unsigned v = k < S2 ? ((hist[k] + 3u) & ~3u) : 0u;
+                    unsigned inc = v;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned o = __shfl_up(inc, off);
+                        if (lane >= off) inc += o;
+                    }
+                    if (k < S2) segs[k] = carry + inc - v;
+                    carry += __shfl(inc, 63);
+                }
+                if (lane == 0) segs[CS_MAX_S2] = carry;
+            }
+            __syncthreads();
+            // --- records into span order; the tag keeps the original position (tmp slot) and the span
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (key[i] >= 0) {
+                    BinRec<T, 3> r = rc[i];
+                    const unsigned tag = (unsigned)(i * 256 + (int)threadIdx.x) | ((unsigned)key[i] << 16);
+                    r.v[3] = __builtin_bit_cast(T, (Tag)tag);
+                    srec[segs[key[i]] + rank[i]] = r;
+                }
+            }
+            // next tile's records travel during this tile's evaluation
+            if (t0 + CS_TILE < sh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long p = t0 + CS_TILE + i * 256 + (long long)threadIdx.x;
+                    rc[i] = rec[p < sh ? p : sh - 1];
+                }
+            }
+            // padding lanes of a segment: a point inside the same cell, tagged invalid (no store)
+            for (int k = threadIdx.x; k < S2; k += blockDim.x) {
+                const unsigned have = hist[k], want = (have + 3u) & ~3u;
+                if (have != want) {
+                    BinRec<T, 3> r;
+                    r.v[0] = d.lo[0];
+                    r.v[1] = d.lo[1];
+                    r.v[2] = tab2[k + d.order[2] - 1];        // left knot of span k: inside the cell
+                    const unsigned tag = 0xffffu | ((unsigned)k << 16);
+                    r.v[3] = __builtin_bit_cast(T, (Tag)tag);
+                    for (unsigned p = have; p < want; ++p) srec[segs[k] + p] = r;
+                }
+            }
+            __syncthreads();
+            // --- evaluation in span order
+            const int total = (int)segs[CS_MAX_S2];
+            for (int g = wave * 64; g < total; g += 256) {
+                const int q = g + lane;
+                const bool live = q < total;
+                const BinRec<T, 3> r = srec[live ? q : total - 1];
+                const unsigned tag = (unsigned)__builtin_bit_cast(Tag, r.v[3]);
+                const int ix2 = (int)(tag >> 16);
+                const unsigned idx = tag & 0xffffu;
+                T b[3][O];
+                basis_fixed<T, O>(stab + d.off[0], d.nk[0], q0 + O, r.v[0], wrt.w[0], b[0]);
+                basis_fixed<T, O>(stab + d.off[1], d.nk[1], q1 + O, r.v[1], wrt.w[1], b[1]);
+                basis_fixed<T, O>(tab2, d.nk[2], ix2 + O, r.v[2], wrt.w[2], b[2]);
+                T res[ND];
+                if constexpr (MFMA) {
+                    cs_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const T *arow = bun + (size_t)(lane & 3) * ncl + ix2;
+                    T w12[O][O];
+#pragma unroll
+                    for (int j = 0; j < O; ++j)
+#pragma unroll
+                        for (int m = 0; m < O; ++m) w12[j][m] = b[1][j] * b[2][m];
+// (Forming the O x O weights of a slab first and issuing its MFMAs back to back - no wait states between a
+                    // product and the MFMA that reads it - needs 64 more registers and measured 4 % slower.)
+#pragma unroll
+                    for (int i = 0; i < O; ++i) {
+#pragma unroll
+                        for (int j = 0; j < O; ++j) {
+                            const T *ap = arow + (size_t)(i * O + j) * 4 * ncl;
+#pragma unroll
+                            for (int m = 0; m < O; ++m) {
+                                const float a = ap[m];
+                                const float wgt = b[0][i] * w12[j][m];
+                                if (((i * O + j) * O + m) & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, wgt, acc1, 0, 0, 0);
+                                else acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, wgt, acc0, 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < ND; ++dd) res[dd] = acc0[dd] + acc1[dd];
+                } else {
+                    int pad[3] = {0, 0, 0};
+                    window_contract<T, 3, O, ND, false>(bun + (long long)ix2 * ND, O * ncl, ncl, pad, b, res);
+                }
+                if (live && idx != 0xffffu) {
+                    BinOut<T, ND> o;
+#pragma unroll
+                    for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);
+                    tmp[t0 + idx] = o;
+                }
+            }
+        }
+    }
+}
+
+// out[dep][n] = tmp[slot[n]][dep]; four independent gathers per lane and iteration.
 template <typename T, int ND>
 __global__ __launch_bounds__(256) void bin_unpermute(const long long N, const unsigned *__restrict__ slot,
                                                      const BinOut<T, ND> *__restrict__ tmp, T *__restrict__ out,
                                                      const long long ostride)
 {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
-        const BinOut<T, ND> r = tmp[slot[n]];
+    const long long stride = (long long)gridDim.x * blockDim.x * BIN_ILP;
+    for (long long n0 = (long long)blockIdx.x * blockDim.x * BIN_ILP + threadIdx.x; n0 < N; n0 += stride) {
+        unsigned p[BIN_ILP];
 #pragma unroll
-        for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + n], r.v[dd]);
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            p[k] = slot[n < N ? n : N - 1];
+        }
+        BinOut<T, ND> r[BIN_ILP];
+#pragma unroll
+        for (int k = 0; k < BIN_ILP; ++k) r[k] = tmp[p[k]];
+#pragma unroll
+        for (int k = 0; k < BIN_ILP; ++k) {
+            const long long n = n0 + (long long)k * blockDim.x;
+            if (n < N) {
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + n], r[k].v[dd]);
+            }
+        }
     }
 }
 

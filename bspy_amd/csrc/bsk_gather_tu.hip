@@ -65,6 +65,13 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         bp.n1 = ((s1 - 1) >> bp.sh1) + 1;
         bp.cells = cells_of(bp.sh0, bp.sh1);
         bp.chunks = (int)std::max<long long>(1, std::min<long long>(BIN_MAX_CHUNKS, (n + BIN_CHUNK_POINTS - 1) / BIN_CHUNK_POINTS));
+        static const int env_chunks = getenv("BSK_BIN_CHUNKS") ? atoi(getenv("BSK_BIN_CHUNKS")) : 0;      // measurement knobs
+        static const int env_block = getenv("BSK_BIN_BLOCK") ? atoi(getenv("BSK_BIN_BLOCK")) : 0;
+        static const int env_unp = getenv("BSK_UNP_GRID") ? atoi(getenv("BSK_UNP_GRID")) : 0;
+        if (env_chunks > 0) bp.chunks = (int)std::min<long long>(std::min(env_chunks, BIN_MAX_CHUNKS), std::max<long long>(1, n / 64));
+        const int bin_block = env_block > 0 ? env_block : BIN_BLOCK;
+        const int ugrid = env_unp > 0 ? env_unp : 2048;
+
         bp.chunk = (n + bp.chunks - 1) / bp.chunks;
         const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
         const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)bp.cells;
@@ -87,6 +94,19 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
         const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
         if (tab_b + bundle_b > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;   // rows of a cell must fit LDS twice per CU
+        // three variables of one order, bins = exact (span0, span1): second grouping by span2 inside the
+        // evaluation workgroup (eval_cellsort); BSK_VARIANT 13 keeps eval_binned_lds, 12 the VALU form
+        bool cellsort = false;
+        size_t cs_lds_mfma = 0, cs_lds_valu = 0;
+        if constexpr (NIND == 3 && !MIXED) {
+            const int S2 = s->ncoef[2] - s->order[2] + 1;
+            const size_t rec_b = 4 * sizeof(T) * (size_t)(CS_TILE + 4 * S2) + sizeof(unsigned) * (size_t)(2 * CS_MAX_S2 + 4);
+            auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+            cs_lds_mfma = tab_b + up16(sizeof(T) * (size_t)O * O * 4 * s->ncoef[2]) + rec_b;
+            cs_lds_valu = tab_b + up16(sizeof(T) * (size_t)O * O * s->nDep * s->ncoef[2]) + rec_b;
+            cellsort = bp.sh0 == 0 && bp.sh1 == 0 && S2 <= CS_MAX_S2 && s->variant != 13 &&
+                       std::max(cs_lds_mfma, cs_lds_valu) <= s->lds_max / 2;
+        }
 #define BINNED_ND(ND)                                                                                                    \
     case ND: {                                                                                                           \
         layout(sizeof(BinOut<T, ND>));                                                                                   \
@@ -101,16 +121,34 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
         s->last_kernel = "cell-order pipeline (eval_binned_lds)";                                                        \
-        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(BIN_BLOCK), lds_count, st, d, bp, tab, prm, n, \
+        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, bp, tab, prm, n, \
                            cell, M, s->bad);                                                                             \
         hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
         hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
-        hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(BIN_BLOCK), sizeof(unsigned) * (size_t)bp.cells, \
+        hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
                            st, bp, prm, n, cell, M, start, rec, slot);                                                   \
+        bool cs_done = false;                                                                                            \
+        if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
+            cs_done = true;                                                                                              \
+            constexpr bool MF = sizeof(T) == 4;                                                                          \
+            if (MF && s->variant != 12) {                                                                                \
+                s->last_kernel = "cell-order pipeline (eval_cellsort, MFMA)";                                            \
+                HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF>, cs_lds_mfma));                                             \
+                hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF>), dim3(egrid), dim3(256), cs_lds_mfma, st, d, bp, tab,   \
+                                   aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);                        \
+            } else {                                                                                                     \
+                s->last_kernel = "cell-order pipeline (eval_cellsort, VALU)";                                            \
+                HIPCHK(allow_lds(eval_cellsort<T, O, ND, false>, cs_lds_valu));                                          \
+                hipLaunchKernelGGL((eval_cellsort<T, O, ND, false>), dim3(egrid), dim3(256), cs_lds_valu, st, d, bp,     \
+                                   tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);                   \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (!cs_done) {                                                                                                  \
         HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, MIXED>, tab_b + bundle_b));                                     \
         hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, MIXED>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d,    \
                            bp, tab, aos, start, rec, n, tmp, w);                                                         \
-        hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(egrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
+        }                                                                                                                \
+        hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(ugrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
     } break;
         switch (s->nDep) {
             BINNED_ND(1) BINNED_ND(2) BINNED_ND(3) BINNED_ND(4)
