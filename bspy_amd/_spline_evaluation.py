@@ -145,12 +145,23 @@ def jacobian(self, uvw):
     return out.astype(self.coefs.dtype, copy=False)
 
 
+def _select_normal(full, indices, normalize, xp):
+    """Reference bspy/_spline_evaluation.py:234-244: only the selected cofactors are built and the result
+    is divided by the norm of THAT vector.  ``full`` = the un-normalised cofactor vector, (rows, ...)."""
+    sel = full[list(indices)]
+    if normalize:
+        sel = sel / xp.sqrt((sel * sel).sum(0))
+    return sel
+
+
 def normal(self, uvw, normalize=True, indices=None):
     """Reference bspy/_spline_evaluation.py:215-246: the normal at one point, or (extension)
     at arrays of points -> shape (len(indices or all), *broadcast_shape)."""
     if abs(self.nInd - self.nDep) != 1:
         raise ValueError("The number of independent variables must be one different than the number of dependent variables.")
     negate = bool(getattr(self, "metadata", {}).get("negateNormal", False))
+    # with an index subset the GPU returns the area-scaled cofactors; selection and normalisation follow here
+    gpu_normalize = normalize and indices is None
     batched = len(uvw) == self.nInd and self.nInd > 0 and not np.isscalar(uvw[0]) and \
         (uvw[0].ndim if hasattr(uvw[0], "ndim") else np.ndim(uvw[0])) > 0
     if batched:
@@ -160,36 +171,71 @@ def normal(self, uvw, normalize=True, indices=None):
             ts = torch.broadcast_tensors(*[(a if _is_torch(a) else torch.as_tensor(np.asarray(a))).to(dev) for a in uvw])
             shape = tuple(ts[0].shape)
             try:
-                out = device_tables(self, dev.index).normal_device(ts, normalize, negate)
+                out = device_tables(self, dev.index).normal_device(ts, gpu_normalize, negate)
             except nv.DomainError as e:
                 cpu = [t.reshape(-1)[e.index].item() for t in ts]
                 raise ValueError(f"Spline evaluation outside domain: {np.atleast_1d(cpu)}") from None
             out = out.view((out.shape[0], *shape))
-        else:
-            arrays = [np.asarray(a) for a in uvw]
-            shape = np.broadcast_shapes(*[a.shape for a in arrays])
-            flat = [np.ascontiguousarray(np.broadcast_to(a, shape), compute_dtype(self)).reshape(-1) for a in arrays]
-            try:
-                out = device_tables(self).normal(flat, normalize, negate)
-            except nv.DomainError as e:
-                raise ValueError(_domain_message(arrays, shape, e.index)) from None
-            out = out.reshape((out.shape[0], *shape)).astype(self.coefs.dtype, copy=False)
-        return out if indices is None else out[list(indices)]
+            return out if indices is None else _select_normal(out, indices, normalize, torch)
+        arrays = [np.asarray(a) for a in uvw]
+        shape = np.broadcast_shapes(*[a.shape for a in arrays])
+        flat = [np.ascontiguousarray(np.broadcast_to(a, shape), compute_dtype(self)).reshape(-1) for a in arrays]
+        try:
+            out = device_tables(self).normal(flat, gpu_normalize, negate)
+        except nv.DomainError as e:
+            raise ValueError(_domain_message(arrays, shape, e.index)) from None
+        out = out.reshape((out.shape[0], *shape))
+        if indices is not None:
+            out = _select_normal(out, indices, normalize, np)
+        return out.astype(self.coefs.dtype, copy=False)
     uvw = np.atleast_1d(uvw)
     if len(uvw) != self.nInd:
         raise ValueError(f"Incorrect number of parameter values: {len(uvw)}")
     try:
-        out = device_tables(self).normal([uvw[i:i + 1] for i in range(self.nInd)], normalize, negate)
+        out = device_tables(self).normal([uvw[i:i + 1] for i in range(self.nInd)], gpu_normalize, negate)
     except nv.DomainError:
         raise ValueError(f"Spline evaluation outside domain: {uvw}") from None
-    out = out[:, 0].astype(self.coefs.dtype, copy=False)
-    return out if indices is None else out[list(indices)]
+    out = out[:, 0]
+    if indices is not None:
+        out = _select_normal(out, indices, normalize, np)
+    return out.astype(self.coefs.dtype, copy=False)
+
+
+def _graph(self):
+    """The graph (u, f(u)) of a scalar-valued spline as a spline with nDep = nInd + 1 (reference
+    bspy/_spline_operations.py:281-288): the Greville abscissae of variable i (reference
+    bspy/_spline_evaluation.py:166-178) are the coefficients of the new dependent variable i.  The
+    reference clamps the spline first (a knot-insertion operation outside the evaluation path); here
+    the knots must already be clamped at both domain ends, as every spline built by the reference's
+    fitting and construction routines is."""
+    from .spline import Spline
+    coefs = np.asarray(self.coefs)
+    new = np.zeros((self.nInd + self.nDep, *coefs.shape[1:]), coefs.dtype)
+    new[self.nInd:] = coefs
+    dom = domain(self)
+    for i in range(self.nInd):
+        k = np.asarray(self.knots[i])
+        o, nc = self.order[i], self.nCoef[i]
+        if not (np.all(k[:o] == k[o - 1]) and np.all(k[nc:] == k[nc])):
+            raise NotImplementedError("curvature of a scalar-valued spline needs knots clamped at the domain ends "
+                                      "(the reference's clamp() is outside this package's evaluation path)")
+        if o == 1:
+            g = 0.5 * (k[1:] + k[:-1])
+        else:
+            g = sum(k[ix:ix + nc] for ix in range(1, o)) / (o - 1)
+        g = np.minimum(dom[i][1], np.maximum(dom[i][0], g))
+        shape = [1] * self.nInd
+        shape[i] = nc
+        new[i] = g.reshape(shape)
+    return Spline(self.nInd, self.nInd + self.nDep, self.order, self.nCoef, self.knots, new, getattr(self, "metadata", {}))
 
 
 def curvature(self, uv):
     """Reference bspy/_spline_evaluation.py:80-107: curvature of a curve (nDep >= 2; signed in
     2-D) or Gaussian curvature of a surface in 3-D, at one point or (extension) at arrays of
-    points.  The reference's nDep == 1 branch (graph of a function) is not covered."""
+    points; a scalar-valued spline (nDep == 1) stands for the graph of the function, as in the reference."""
+    if self.nDep == 1 and self.nInd in (1, 2):
+        self = _graph(self)                     # reference :81-82: curvature of the graph of the function
     if not ((self.nInd == 1 and self.nDep >= 2) or (self.nInd == 2 and self.nDep == 3)):
         raise NotImplementedError("curvature needs a curve with nDep >= 2 or a surface with nDep == 3")
     if self.nInd == 1 and (np.isscalar(uv) or np.ndim(uv) == 0):

@@ -20,8 +20,8 @@ Documented deviations from the reference:
     silently truncates, e.g. Spline(1,1,[4],[4],[[0,0,0,0,1,1,1,1]],[[0.,1,2,3]])(0.5) -> 0);
   * batched calls with nDep == 1 and N-D inputs return the full broadcast shape (the
     reference returns only column 0 of each row);
-  * ufunc keyword arguments (where=, out=) of the reference's np.frompyfunc wrapper are
-    not supported;
+  * of the ufunc keyword arguments of the reference's np.frompyfunc wrapper, where= and out= are
+    honoured (out= also takes float arrays); the others (casting=, order=, ...) raise TypeError;
   * mixed float32/float64 inputs are computed in float64;
   * CUDA/HIP torch tensors are accepted as parameters (results stay on the GPU) and
     jacobian() accepts arrays of points (the reference's is single-point).
@@ -92,11 +92,52 @@ class Spline:
         """B-spline (derivative) basis values of one segment; reference spline.py:207-252."""
         return _ev.bspline_values(knot, knots, splineOrder, u, derivativeOrder, taylorCoefs)
 
+    def _batched_masked(self, with_respect_to, uvw, where, out, device):
+        """The ufunc keyword arguments the reference's np.frompyfunc call honours (bspy/spline.py:943-947):
+        ``where`` - only the selected points are evaluated (an out-of-domain value under a False entry does not
+        raise); unselected results are NaN, or what ``out`` held; ``out`` - nDep arrays of the broadcast shape
+        (one array when nDep == 1) that receive the results (object arrays as np.frompyfunc needs, or float
+        arrays).  Returns new arrays in the coefficients' dtype, as the reference does."""
+        arrays = [np.asarray(a) for a in uvw]
+        mask = np.asarray(True if where is None else where, dtype=bool)
+        shape = np.broadcast_shapes(mask.shape, *[a.shape for a in arrays])
+        outs = None
+        if out is not None:
+            outs = (out,) if not isinstance(out, (tuple, list)) else tuple(out)
+            if len(outs) != self.nDep:
+                raise ValueError(f"out must hold {self.nDep} arrays")
+            shape = np.broadcast_shapes(shape, *[o.shape for o in outs])
+            for o in outs:
+                if o.shape != shape:
+                    raise ValueError("non-broadcastable output operand")
+        sel = np.broadcast_to(mask, shape)
+        res = np.full((self.nDep, *shape), np.nan, _ev.compute_dtype(self))
+        if outs is not None:
+            for d, o in enumerate(outs):
+                res[d] = np.asarray(o, dtype=res.dtype)
+        pts = [np.broadcast_to(a, shape)[sel] for a in arrays]
+        if pts[0].size:
+            try:
+                res[:, sel] = _ev.evaluate_batch(self, with_respect_to, pts, device=device)
+            except ValueError as e:
+                raise ValueError(str(e)) from None
+        if outs is not None:
+            for d, o in enumerate(outs):
+                o[...] = res[d]
+        res = res.astype(self.coefs.dtype, copy=False)
+        return tuple(res[d] for d in range(self.nDep)) if self.nDep > 1 else res[0]
+
     def _batched(self, with_respect_to, uvw, kwargs):
         device = kwargs.pop("device", None)
         check = kwargs.pop("check", True)
+        where = kwargs.pop("where", None)
+        out = kwargs.pop("out", None)
         if kwargs:
-            raise TypeError("ufunc keyword arguments are not supported by bspy_amd: " + ", ".join(sorted(kwargs)))
+            raise TypeError("ufunc keyword arguments other than where= / out= are not supported by bspy_amd: " + ", ".join(sorted(kwargs)))
+        if where is not None or out is not None:
+            if any(_ev._is_torch(a) for a in uvw):
+                raise TypeError("where= / out= take NumPy arrays")
+            return self._batched_masked(with_respect_to, uvw, where, out, device)
         out = _ev.evaluate_batch(self, with_respect_to, uvw, device=device, check=check)
         if _ev._is_torch(out):
             import torch

@@ -249,8 +249,68 @@ def tess_golden(bspy):
     return out
 
 
+def extras_golden(bspy):
+    """Round-2 fixtures recorded from the reference (inputs regenerated from seeds by the tests):
+      * Spline.normal with index subsets, normalised and not (bspy/_spline_evaluation.py:215-246: the
+        normalisation divides by the norm of the SELECTED cofactors),
+      * Spline.curvature of scalar-valued splines (nDep == 1: the reference evaluates the curvature of the
+        graph of the function, bspy/_spline_evaluation.py:81-82 -> graph(), bspy/_spline_operations.py:281-288),
+      * the collocation matrix A that the reference's least_squares assembles (bspy/_spline_fitting.py:736-751),
+        captured from its own call of numpy.linalg.lstsq (repeated parameter values = derivative rows).
+      * evaluation with ufunc keyword arguments where= / out= (bspy/spline.py:943-947)."""
+    out = {}
+    rng = np.random.default_rng(2024)
+    # --- normal with indices
+    ku = np.concatenate([np.zeros(4), np.linspace(0, 1, 6)[1:-1], np.ones(4)])
+    kv = np.concatenate([np.zeros(3), np.array([0.3, 0.55]), np.ones(3)])
+    surf = bspy.Spline(2, 3, [4, 3], [8, 5], [ku, kv], rng.standard_normal((3, 8, 5)))
+    pts = rng.random((40, 2))
+    out["normal_surf_knots0"], out["normal_surf_knots1"], out["normal_surf_coefs"] = ku, kv, surf.coefs
+    out["normal_pts"] = pts
+    for name, idx in (("0_2", [0, 2]), ("2", [2]), ("1_0", [1, 0])):
+        for nz in (True, False):
+            out[f"normal_idx_{name}_{int(nz)}"] = np.array([surf.normal(p, nz, idx) for p in pts])
+    curve2 = bspy.Spline(1, 2, [4], [8], [ku], rng.standard_normal((2, 8)))
+    out["normal_curve_coefs"] = curve2.coefs
+    out["normal_curve_idx_1"] = np.array([curve2.normal([u], True, [1]) for u in pts[:, 0]])
+    # --- curvature of graphs (nDep == 1)
+    f1 = bspy.Spline(1, 1, [4], [8], [ku], rng.standard_normal((1, 8)))
+    out["graph_curve_coefs"] = f1.coefs
+    out["graph_curve_curvature"] = np.array([f1.curvature(u) for u in pts[:, 0]])
+    f2 = bspy.Spline(2, 1, [4, 3], [8, 5], [ku, kv], rng.standard_normal((1, 8, 5)))
+    out["graph_surf_coefs"] = f2.coefs
+    out["graph_surf_curvature"] = np.array([f2.curvature(p) for p in pts])
+    # --- collocation matrix captured from least_squares
+    captured = []
+    real = np.linalg.lstsq
+
+    def spy(A, b, rcond=None):
+        captured.append(np.array(A))
+        return real(A, b, rcond=rcond)
+
+    u = np.sort(rng.random(30))
+    u = np.concatenate([u[:10], [u[10], u[10], u[10]], u[11:20], [u[20], u[20]], u[21:]])      # Hermite rows
+    kn = np.concatenate([np.zeros(5), np.sort(rng.random(7)), np.ones(5)])
+    np.linalg.lstsq = spy
+    try:
+        bspy.Spline.least_squares([u], rng.standard_normal((2, len(u))), order=[5], knots=[kn], fixEnds=False)
+    finally:
+        np.linalg.lstsq = real
+    out["colloc_u"], out["colloc_knots"], out["colloc_A"] = u, kn, captured[0]
+    # --- ufunc keyword arguments
+    uu, vv = rng.random(12), rng.random(12)
+    mask = rng.random(12) > 0.4
+    res = surf.evaluate(uu, vv, where=mask)
+    out["where_u"], out["where_v"], out["where_mask"] = uu, vv, mask
+    out["where_result"] = np.array([[r[i] if mask[i] else np.nan for i in range(12)] for r in res], np.float64)
+    return out
+
+
 def main():
     bspy = load_reference()
+    if "--only-extras" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "extras.npz"), **extras_golden(bspy))
+        return
     if "--only-tess" in sys.argv:
         np.savez_compressed(os.path.join(HERE, "tess.npz"), **tess_golden(bspy))
         return
@@ -282,6 +342,7 @@ def main():
         json.dump(api_semantics(bspy), f, indent=1)
     np.savez_compressed(os.path.join(HERE, "block.npz"), **block_golden(bspy))
     np.savez_compressed(os.path.join(HERE, "tess.npz"), **tess_golden(bspy))
+    np.savez_compressed(os.path.join(HERE, "extras.npz"), **extras_golden(bspy))
     print("golden fixtures written to", HERE)
 
 

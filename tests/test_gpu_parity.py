@@ -262,6 +262,16 @@ def test_constructor_forms_and_mutation(golden_api):
     assert np.abs(after - before).max() > 1e-3
     fresh = Spline(2, 3, [3, 4], [4, 5], k2, ref.coefs.copy())
     assert np.array_equal(after, fresh([0.3, 0.6]))
+    # swaps of round values in place (a checksum that is linear mod 2^64 misses them: 0.0 <-> 2.0, 1.0 <-> 2.0)
+    sw = Spline(1, 2, [2], [4], [[0, 0, 1 / 3, 2 / 3, 1, 1]], np.array([[0.0, 2.0, 2.0, 0.0], [0.0, 0.0, 2.0, 1.0]]))
+    a0 = sw(0.1).copy()
+    sw.coefs[0, 0], sw.coefs[0, 1] = 2.0, 0.0
+    a1 = sw(0.1).copy()
+    assert np.abs(a1 - a0).max() > 0.5
+    sw.coefs[1, 2], sw.coefs[1, 3] = 1.0, 2.0
+    assert np.array_equal(sw(0.9), Spline(1, 2, [2], [4], sw.knots, sw.coefs.copy())(0.9)) and abs(sw(0.9)[1] - 1.7) < 1e-12
+    sw.knots[0][2], sw.knots[0][3] = 0.25, 0.75                      # knots are mutable too
+    assert np.array_equal(sw(0.5), Spline(1, 2, [2], [4], [sw.knots[0].copy()], sw.coefs.copy())(0.5))
     # integer inputs are promoted to float64 (documented deviation)
     si = Spline(1, 1, [4], [4], [[0, 0, 0, 0, 1, 1, 1, 1]], [[0, 1, 2, 3]])
     assert abs(si(0.5)[0] - 1.5) < 1e-14
@@ -583,11 +593,51 @@ def test_reference_json_files_evaluate():
                 got = np.stack(got) if isinstance(got, tuple) else np.asarray(got)[None, :]
                 orc, bad = oracle.c_evaluate(s.order, s.nCoef, knots, coefs, w, [u])
                 assert bad == -1
-                # second derivatives of these order-7 curves (knot spacing down to 6e-5) are
-                # ill-conditioned: the reference's own fp64 result is 6e-5 (7e-9 of the scale)
-                # away from an extended-precision evaluation, and so is ours
-                tol = 1e-11 if w[0] < 2 else 2e-8
-                assert np.abs(got - orc).max() <= tol * _scale(orc), (name, w)
+                if w[0] < 2:
+                    assert np.abs(got - orc).max() <= 1e-11 * _scale(orc), (name, w)
+                    continue
+                # Second derivatives of these order-7 curves (knot spacing down to 6e-5) are ill-conditioned: fp64
+                # rounding alone moves them by ~1e-8 of their scale.  Measured, not assumed: the reference's
+                # algorithm restated in extended precision (np.longdouble) is the yardstick, and the GPU result
+                # must be as close to it as the fp64 oracle (= the reference's arithmetic) is, within a factor 4.
+                ext = _curve_derivative_longdouble(s.order[0], knots[0], coefs, w[0], u)
+                scale = _scale(orc)
+                d_orc = float(np.abs(orc - ext).max()) / scale
+                d_gpu = float(np.abs(got - ext).max()) / scale
+                assert d_orc <= 1e-7, (name, d_orc)                       # the yardstick itself is sane
+                assert d_gpu <= max(4.0 * d_orc, 1e-11), (name, w, d_gpu, d_orc)
+
+
+def _curve_derivative_longdouble(order, knots, coefs, deriv, us):
+    """Reference bspy/_spline_evaluation.py:4-27 + :109-133 for a curve, every operation in np.longdouble."""
+    L = np.longdouble
+    k = knots.astype(L)
+    c = coefs.astype(L)
+    out = np.zeros((c.shape[0], len(us)), L)
+    ncoef = len(k) - order
+    for n, uf in enumerate(us):
+        u = L(uf)
+        ix = int(np.searchsorted(knots, uf, side="right"))
+        ix = min(max(ix, order), ncoef)
+        b = np.zeros(order, L)
+        if deriv < order:
+            b[-1] = 1
+            for degree in range(1, order - deriv):
+                bi = order - degree
+                for i in range(ix - degree, ix):
+                    alpha = (u - k[i]) / (k[i + degree] - k[i])
+                    b[bi - 1] += (1 - alpha) * b[bi]
+                    b[bi] *= alpha
+                    bi += 1
+            for degree in range(order - deriv, order):
+                bi = order - degree
+                for i in range(ix - degree, ix):
+                    alpha = L(degree) / (k[i + degree] - k[i])
+                    b[bi - 1] += -alpha * b[bi]
+                    b[bi] *= alpha
+                    bi += 1
+        out[:, n] = c[:, ix - order:ix] @ b
+    return out
 
 
 NORMAL_CASES = [n for n, c in CASES.items() if abs(c.nInd - c.nDep) == 1 and max(c.nInd, c.nDep) <= 4]
@@ -617,7 +667,8 @@ def test_normal_against_reference(name, golden_parity):
         one = s.normal([float(p[3]) for p in c.points])               # single point, reference call style
         assert one.shape == (max(c.nInd, c.nDep),)
         assert np.abs(one - golden_parity[f"{name}/normal_unit"][3]).max() <= tol
-        assert np.array_equal(s.normal([float(p[3]) for p in c.points], indices=(1, 0)), one[[1, 0]])
+        area = s.normal([float(p[3]) for p in c.points], False)
+        assert np.array_equal(s.normal([float(p[3]) for p in c.points], False, indices=(1, 0)), area[[1, 0]])
     with pytest.raises(ValueError, match="one different"):
         Spline(2, 2, [2, 2], [2, 2], [[0, 0, 1, 1.0]] * 2, np.zeros((2, 2, 2))).normal([0.5, 0.5])
 
@@ -893,6 +944,7 @@ def test_random_shapes_against_oracle():
     trials = int(os.environ.get("BSK_SOAK", "70"))              # BSK_SOAK=1000 for a longer soak with another seed
     rng = np.random.default_rng(20260 if trials == 70 else 777)
     checked = 0
+    worst = {np.float32: 0.0, np.float64: 0.0}
     for trial in range(trials):
         nind = int(rng.choice([1, 2, 2, 2, 3, 3, 4, 5]))
         omax_allowed = {1: 9, 2: 8, 3: 6, 4: 4, 5: 3}[nind]
@@ -914,7 +966,9 @@ def test_random_shapes_against_oracle():
         coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
         t = DeviceSpline(order, ncoef, knots, coefs, dt)
         dom = [(float(k[o - 1]), float(k[c])) for k, o, c in zip(knots, order, ncoef)]
-        tol = 5e-5 if dt == np.float32 else 1e-11
+        # of the result scale.  fp64: the north_star bound is 1e-10; observed worst over the sweep 1.3e-15
+        # (fp32 8.6e-7), printed below
+        tol = 2e-5 if dt == np.float32 else 1e-12
         for n in (257, 70_001):
             pts = [(lo + (hi - lo) * rng.random(n)).astype(dt) for lo, hi in dom]
             pts = [np.clip(p, dt(lo), dt(hi)) for p, (lo, hi) in zip(pts, dom)]
@@ -923,14 +977,19 @@ def test_random_shapes_against_oracle():
                 got = t.evaluate(pts, w)
                 orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, pts)
                 assert bad == -1
-                assert np.abs(got - orc).max() <= tol * 30 * _scale(orc), (trial, order, ncoef, ndep, dt, n, w)
+                err = float(np.abs(got - orc).max()) / _scale(orc)
+                worst[dt] = max(worst[dt], err)
+                assert err <= tol, (trial, order, ncoef, ndep, dt, n, w, err)
             if n == 257 or nind <= 3:
                 got = t.jacobian(pts)
                 orc, _ = oracle.c_jacobian(order, ncoef, knots, coefs, pts)
-                assert np.abs(got - orc).max() <= tol * 30 * _scale(orc), (trial, order, ncoef, ndep, dt, n, "jac")
+                err = float(np.abs(got - orc).max()) / _scale(orc)
+                worst[dt] = max(worst[dt], err)
+                assert err <= tol, (trial, order, ncoef, ndep, dt, n, "jac", err)
             checked += 1
         t.close()
     assert checked == 2 * trials
+    print(f"random shapes: worst error of the result scale fp64 {worst[np.float64]:.2e}, fp32 {worst[np.float32]:.2e}")
 
 
 def test_tessellate_more_patches_than_one_launch_takes():
@@ -1084,3 +1143,87 @@ def test_uniform_knot_path(order, ncoef, dom, clamps, monkeypatch):
     t.update(knots, coefs2)
     orc2, _ = oracle.c_evaluate((order, order), ncoef, knots, coefs2, [0, 0], pts)
     assert np.abs(t.evaluate(pts) - orc2).max() <= 1e-12 * _scale(orc2)
+
+
+@pytest.fixture(scope="module")
+def golden_extras():
+    return np.load(os.path.join(ROOT, "tests", "golden", "extras.npz"))
+
+
+def test_normal_index_subsets_against_reference(golden_extras):
+    """Spline.normal(uvw, normalize, indices): the reference builds only the selected cofactors and divides
+    by the norm of THAT vector (bspy/_spline_evaluation.py:234-244): indices=[2] of a unit 'normal' is +-1."""
+    g = golden_extras
+    surf = Spline(2, 3, [4, 3], [8, 5], [g["normal_surf_knots0"], g["normal_surf_knots1"]], g["normal_surf_coefs"])
+    pts = g["normal_pts"]
+    for name, idx in (("0_2", [0, 2]), ("2", [2]), ("1_0", [1, 0])):
+        for nz in (True, False):
+            ref = g[f"normal_idx_{name}_{int(nz)}"]
+            one = np.array([surf.normal(p, nz, idx) for p in pts[:5]])               # the reference's single-point call
+            assert one.shape == ref[:5].shape and np.abs(one - ref[:5]).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+            many = surf.normal([pts[:, 0], pts[:, 1]], nz, idx)                      # batched extension
+            assert many.shape == ref.T.shape and np.abs(many - ref.T).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert np.abs(np.abs(surf.normal([pts[:, 0], pts[:, 1]], True, [2])) - 1.0).max() <= 1e-14
+    curve = Spline(1, 2, [4], [8], [g["normal_surf_knots0"]], g["normal_curve_coefs"])
+    got = curve.normal([pts[:, 0]], True, [1])
+    assert np.abs(got - g["normal_curve_idx_1"].T).max() <= 1e-13
+    import torch
+    tu, tv = torch.as_tensor(pts[:, 0], device="cuda"), torch.as_tensor(pts[:, 1], device="cuda")
+    t = surf.normal([tu, tv], True, [0, 2])
+    assert t.is_cuda and np.abs(t.cpu().numpy() - g["normal_idx_0_2_1"].T).max() <= 1e-12
+
+
+def test_curvature_of_scalar_valued_splines(golden_extras):
+    """nDep == 1: the reference evaluates the curvature of the GRAPH of the function
+    (bspy/_spline_evaluation.py:81-82 -> graph(), Greville abscissae as the new coordinates)."""
+    g = golden_extras
+    pts = g["normal_pts"]
+    f1 = Spline(1, 1, [4], [8], [g["normal_surf_knots0"]], g["graph_curve_coefs"])
+    ref = g["graph_curve_curvature"]
+    assert np.abs(f1.curvature([pts[:, 0]]) - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    assert abs(f1.curvature(float(pts[3, 0])) - ref[3]) <= 1e-11 * max(1.0, abs(ref[3]))
+    f2 = Spline(2, 1, [4, 3], [8, 5], [g["normal_surf_knots0"], g["normal_surf_knots1"]], g["graph_surf_coefs"])
+    ref = g["graph_surf_curvature"]
+    got = f2.curvature([pts[:, 0], pts[:, 1]])
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    with pytest.raises(NotImplementedError):
+        Spline(1, 1, [3], [4], [[-1.0, 0, 0, 0.5, 1, 1, 2.0]], np.ones((1, 4))).curvature(0.25)    # not clamped
+
+
+def test_collocation_matrix_against_reference(golden_extras):
+    """The matrix the reference's least_squares assembles (bspy/_spline_fitting.py:736-751), captured from
+    its own numpy.linalg.lstsq call: Hermite rows for repeated parameter values included."""
+    g = golden_extras
+    A = bspy_amd.collocation_matrix(g["colloc_knots"], 5, g["colloc_u"])
+    ref = g["colloc_A"]
+    assert A.shape == ref.shape
+    assert np.abs(A - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.array_equal(A != 0, ref != 0) or np.abs(A - ref)[(A != 0) != (ref != 0)].max() <= 1e-300
+
+
+def test_ufunc_keyword_arguments(golden_extras):
+    """where= / out= of the batched wrappers (bspy/spline.py:943-947: np.frompyfunc honours them): only the
+    selected points are evaluated, the rest is NaN or keeps what out held; out arrays receive the results."""
+    g = golden_extras
+    surf = Spline(2, 3, [4, 3], [8, 5], [g["normal_surf_knots0"], g["normal_surf_knots1"]], g["normal_surf_coefs"])
+    u, v, mask, ref = g["where_u"], g["where_v"], g["where_mask"], g["where_result"]
+    res = surf.evaluate(u, v, where=mask)
+    assert isinstance(res, tuple) and len(res) == 3
+    got = np.stack(res)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) <= 1e-13
+    bad_u = u.copy()
+    bad_u[~mask] = 7.0                                   # outside the domain, but never evaluated
+    assert np.array_equal(np.stack(surf(bad_u, v, where=mask)), got, equal_nan=True)
+    with pytest.raises(ValueError, match="outside domain"):
+        surf(bad_u, v)
+    outs = tuple(np.full(12, 7.0, dtype=object) for _ in range(3))       # the reference needs object arrays here
+    res = surf.evaluate(u, v, where=mask, out=outs)
+    full = np.stack(surf(u, v))
+    for d in range(3):
+        assert np.array_equal(res[d][~mask], np.full((~mask).sum(), 7.0)) and np.array_equal(res[d][mask], full[d][mask])
+        assert all(float(outs[d][i]) == res[d][i] for i in range(12))
+    fouts = tuple(np.zeros(12) for _ in range(3))                         # float arrays are accepted too (extension)
+    surf.derivative([1, 0], u, v, out=fouts)
+    assert np.array_equal(np.stack(fouts), np.stack(surf.derivative([1, 0], u, v)))
+    with pytest.raises(TypeError):
+        surf(u, v, casting="unsafe")

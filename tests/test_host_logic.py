@@ -117,7 +117,7 @@ def test_arity_and_kwargs_errors():
     with pytest.raises(ValueError, match="Incorrect number of parameter values: 3"):
         s2.jacobian([0.1, 0.2, 0.3])
     with pytest.raises(TypeError, match="ufunc keyword"):
-        s2(np.zeros(4), np.zeros(4), where=np.ones(4, bool))
+        s2(np.zeros(4), np.zeros(4), casting="unsafe")
 
 
 def test_grid_detection():
