@@ -291,6 +291,7 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->in_ws.release();
     s->out_ws.release();
     s->aux_ws.release();
+    s->curv_ws.release();
     s->bin_ws.release();
     s->uni_img.release();
     if (s->pin) (void)hipHostFree(s->pin);
@@ -1020,6 +1021,22 @@ static bsk_status read_bad(bsk_spline s, hipStream_t st, int64_t *first_bad)
     return BSK_OK;
 }
 
+// Grow a per-handle device workspace.  Growth frees and allocates (a device-wide synchronisation) and cannot be
+// recorded by a stream capture: a capturing stream gets a clear error instead of a broken capture (run the
+// call once outside the capture, the workspace then has its size).  The workspaces belong to the handle:
+// one handle is used from one stream at a time (include/bspy_amd.h).
+static bsk_status ws_reserve(DevBuf &b, size_t bytes, hipStream_t st)
+{
+    if (bytes <= b.cap) return BSK_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(BSK_ERR_INVALID, "a workspace of this spline handle has to grow, which a stream capture cannot record: "
+                                     "run the same call once outside the capture first");
+    (void)hipGetLastError();
+    HIPCHK(b.reserve(bytes));
+    return BSK_OK;
+}
+
 extern "C" bsk_status bsk_domain_status(bsk_spline s, void *stream, int64_t *first_bad)
 {
     if (!s) return fail(BSK_ERR_INVALID, "NULL handle");
@@ -1453,18 +1470,18 @@ static bsk_status run_normal(bsk_spline s, const void *const *uvw, long long n, 
         return BSK_OK;
     };
     if (mem == BSK_HOST && n <= small_call_points()) {
-        if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)n * s->nDep * s->nInd));
+        if (!fused) if (bsk_status r_ = ws_reserve(s->aux_ws, sizeof(T) * (size_t)n * s->nDep * s->nInd, st); r_ != BSK_OK) return r_;
         return run_small<T>(s, uvw, n, big, out, st, first_bad,
                             [&](const Params<T> &prm, T *dout) { return normal_chunk(prm, n, dout, st); });
     }
     if (mem == BSK_HOST && n >= PIPE_MIN_POINTS) {
         if (CopyPool *pool = copy_pool()) {
-            if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)PIPE_CHUNK * s->nDep * s->nInd));
+            if (!fused) if (bsk_status r_ = ws_reserve(s->aux_ws, sizeof(T) * (size_t)PIPE_CHUNK * s->nDep * s->nInd, st); r_ != BSK_OK) return r_;
             HIPCHK(hipStreamSynchronize(st));
             return run_piped<T>(s, pool, uvw, n, big, out, first_bad, normal_chunk);
         }
     }
-    if (!fused) HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)chunk * s->nDep * s->nInd));
+    if (!fused) if (bsk_status r_ = ws_reserve(s->aux_ws, sizeof(T) * (size_t)chunk * s->nDep * s->nInd, st); r_ != BSK_OK) return r_;
     T *djac = static_cast<T *>(s->aux_ws.p);
     T *din = nullptr, *dout = static_cast<T *>(out);
     if (mem == BSK_HOST) {
@@ -1543,10 +1560,9 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
     const bool fused = surface && s->nDep == 3 && rowrot_applies<T>(s);   // curv_rowrot: no intermediates at all
     const int nbuf = fused ? 0 : (surface ? 6 : 2);      // derivative buffers (+ normal) of nDep rows each
     const long long chunk = std::min<long long>(n, mem == BSK_HOST ? host_chunk_points() : (1ll << 22));
-    DevBuf work;                                         // derivative workspace (freed on return)
-    HIPCHK(work.reserve(sizeof(T) * (size_t)chunk * s->nDep * nbuf));
-    struct Guard { DevBuf &b; ~Guard() { b.release(); } } guard{work};
-    T *w = static_cast<T *>(work.p);
+    // derivative workspace: persistent on the handle (no allocation, free or synchronisation per call)
+    if (bsk_status r_ = ws_reserve(s->curv_ws, std::max<size_t>(16, sizeof(T) * (size_t)chunk * s->nDep * nbuf), st); r_ != BSK_OK) return r_;
+    T *w = static_cast<T *>(s->curv_ws.p);
     T *din = nullptr, *dout = static_cast<T *>(out);
     if (mem == BSK_HOST) {
         HIPCHK(s->in_ws.reserve(sizeof(T) * (size_t)chunk * s->nInd));
@@ -1615,7 +1631,7 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
             if (rowrot_applies<T>(s)) {
                 if ((r = launch_jac_rowrot<T, true>(s, prm, m, w + 5 * one, 1, 0, st)) != BSK_OK) return r;
             } else {
-                HIPCHK(s->aux_ws.reserve(sizeof(T) * (size_t)m * s->nDep * s->nInd));
+                if (bsk_status r_ = ws_reserve(s->aux_ws, sizeof(T) * (size_t)m * s->nDep * s->nInd, st); r_ != BSK_OK) return r_;
                 T *djac = static_cast<T *>(s->aux_ws.p);
                 if ((r = dispatch_jac<T>(s, prm, m, djac, st)) != BSK_OK) return r;
                 hipLaunchKernelGGL((normal_epilogue<T>), dim3(grid), dim3(block), 0, st, djac, 2, 3, m, 1, 0, w + 5 * one);
@@ -1635,8 +1651,6 @@ static bsk_status run_curvature(bsk_spline s, const void *const *uvw, long long 
             if (r != BSK_OK) return r;
         }
     }
-    // the workspace is released when this function returns: its kernels must have finished
-    HIPCHK(hipStreamSynchronize(st));
     return BSK_OK;
 }
 
@@ -1681,7 +1695,7 @@ static bsk_status run_grid(bsk_spline s, const int *wrt, const void *const *grid
     const size_t par_b = mem == BSK_HOST ? ((sizeof(T) * (size_t)npar + 15) & ~(size_t)15) : 0;
     const size_t row_b = (sizeof(T) * (size_t)nrow + 15) & ~(size_t)15;
     const size_t ix_b = (sizeof(int) * (size_t)npar + 15) & ~(size_t)15;
-    HIPCHK(s->aux_ws.reserve(par_b + row_b + ix_b + (size_t)npar + 16));
+    if (bsk_status r_ = ws_reserve(s->aux_ws, par_b + row_b + ix_b + (size_t)npar + 16, st); r_ != BSK_OK) return r_;
     char *base = static_cast<char *>(s->aux_ws.p);
     T *dpar = reinterpret_cast<T *>(base);
     T *rows = reinterpret_cast<T *>(base + par_b);
@@ -1806,7 +1820,7 @@ static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *co
     const size_t par_b = mem == BSK_HOST ? ((sizeof(T) * (size_t)npar + 15) & ~(size_t)15) : 0;
     const size_t row_b = (sizeof(T) * (size_t)nrow + 15) & ~(size_t)15;
     const size_t ix_b = (sizeof(int) * (size_t)npar + 15) & ~(size_t)15;
-    HIPCHK(s->aux_ws.reserve(par_b + 2 * row_b + 2 * ix_b + 2 * (size_t)npar + 32));
+    if (bsk_status r_ = ws_reserve(s->aux_ws, par_b + 2 * row_b + 2 * ix_b + 2 * (size_t)npar + 32, st); r_ != BSK_OK) return r_;
     char *base = static_cast<char *>(s->aux_ws.p);
     T *dpar = reinterpret_cast<T *>(base);
     T *rows = reinterpret_cast<T *>(base + par_b);

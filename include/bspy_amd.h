@@ -23,6 +23,14 @@
  *  - the caller owns every buffer it passes; the library owns the device tables
  *    behind a bsk_spline handle.  Handles are not thread safe; distinct handles are
  *    independent.
+ *  - a handle also owns scratch workspaces (jacobian rows of a non-fused normal, derivative passes of a
+ *    non-fused curvature, grid basis rows, the cell-order pipeline's records).  They are shared by every call
+ *    on the handle, so ONE handle is used from ONE stream at a time (create a second handle for a second
+ *    stream).  A workspace grows (free + allocate) only when a call needs more than any call before it; such
+ *    growth cannot be recorded by a stream capture and returns BSK_ERR_INVALID with a message saying so - run
+ *    the call once outside the capture.  With that, every BSK_DEVICE call only enqueues kernels on `stream`
+ *    (the cell-order pipeline of large tables sizes its workspace per batch and declines under capture: the
+ *    call then runs the gather kernel).
  */
 #ifndef BSPY_AMD_H
 #define BSPY_AMD_H

@@ -65,6 +65,14 @@ def test_evaluate_derivative_against_reference(name, golden_parity):
         orc, bad = oracle.c_evaluate(c.order, c.nCoef, c.knots, c.coefs, list(w), c.points)
         assert bad == -1
         assert np.abs(out - orc).max() <= tol * _scale(orc), (name, w)
+        if not _is_f32(c) and tol > 1e-12:
+            # mixed fp32 / fp64 inputs: the reference rounds its basis to fp32, the product computes in fp64
+            # (documented deviation) - so it agrees with the reference to fp32 rounding (above) and with the
+            # SAME algorithm carried out in fp64 on the promoted inputs to the fp64 bar
+            k64 = [np.asarray(k, np.float64) for k in c.knots]
+            p64 = [np.asarray(p, np.float64) for p in c.points]
+            o64, _ = oracle.c_evaluate(c.order, c.nCoef, k64, np.asarray(c.coefs, np.float64), list(w), p64)
+            assert np.abs(out - o64).max() <= 1e-12 * _scale(o64), (name, w, "fp64 restatement")
     # plain evaluation with wrt == None is the same kernel path as all-zero wrt
     zero = tuple([0] * c.nInd)
     if zero in c.wrts:
@@ -722,6 +730,56 @@ def test_hip_graph_capture_of_device_calls():
     torch.cuda.synchronize()
     assert torch.equal(out, expect.flip(1)) and torch.equal(jac, expect_j.flip(2))
     t.domain_status()
+    # normal and curvature: fused kernels (surface in 3-D on the LDS image) and the workspace forms (a curve's
+    # curvature = two derivative passes + epilogue in a handle workspace that the warm-up call sized)
+    nrm = torch.empty((3, u.numel()), dtype=torch.float64, device="cuda")
+    crv = torch.empty((u.numel(),), dtype=torch.float64, device="cuda")
+    cc = next(x for _, x in sorted(CASES.items()) if x.nInd == 1 and x.nDep >= 2 and x.order[0] >= 3 and x.knots[0].dtype == np.float64
+              and x.coefs.dtype == np.float64)
+    tc = Spline(cc.nInd, cc.nDep, cc.order, cc.nCoef, cc.knots, cc.coefs).device_tables()
+    w = torch.as_tensor(np.asarray(cc.points[0], np.float64), device="cuda")
+    ccrv = torch.empty((w.numel(),), dtype=torch.float64, device="cuda")
+    t.normal_device([u, v], out=nrm, check=False)
+    t.curvature_device([u, v], out=crv, check=False)
+    tc.curvature_device([w], out=ccrv, check=False)
+    torch.cuda.synchronize()
+    e_n, e_c, e_cc = nrm.clone(), crv.clone(), ccrv.clone()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        t.normal_device([u, v], out=nrm, check=False)
+        t.curvature_device([u, v], out=crv, check=False)
+        tc.curvature_device([w], out=ccrv, check=False)
+    nrm.zero_(); crv.zero_(); ccrv.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(nrm, e_n) and torch.equal(crv, e_c) and torch.isfinite(e_cc).any()
+    assert torch.allclose(ccrv, e_cc, rtol=0, atol=0, equal_nan=True)
+    # a large-table spline: the cell-order pipeline sizes a workspace per batch and therefore declines under
+    # capture; the call falls back to the gather kernel and stays capturable
+    rng = np.random.default_rng(3)
+    kl = [cases.clamped_uniform_knots(3, 300), cases.clamped_uniform_knots(3, 300)]
+    big = DeviceSpline((3, 3), (300, 300), kl, rng.standard_normal((2, 300, 300)))
+    n = 1 << 18
+    bu, bv = torch.rand(n, dtype=torch.float64, device="cuda"), torch.rand(n, dtype=torch.float64, device="cuda")
+    bo = torch.empty((2, n), dtype=torch.float64, device="cuda")
+    big.evaluate_device([bu, bv], out=bo, check=False)
+    torch.cuda.synchronize()
+    e_b = bo.clone()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):
+        big.evaluate_device([bu, bv], out=bo, check=False)
+    bo.zero_()
+    g3.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bo, e_b)
+    # a workspace that would have to grow inside a capture is refused with a clear message (last: the failed
+    # capture is abandoned)
+    fresh = DeviceSpline(cc.order, cc.nCoef, cc.knots, cc.coefs)
+    g0 = torch.cuda.CUDAGraph()
+    with pytest.raises(bspy_amd.BskError, match="outside the capture"):
+        with torch.cuda.graph(g0):
+            fresh.curvature_device([w], out=ccrv, check=False)
+    torch.cuda.synchronize()
 
 
 CURVATURE_CASES = [n for n, c in CASES.items() if (c.nInd == 1 and c.nDep >= 2) or (c.nInd == 2 and c.nDep == 3)]
