@@ -1937,8 +1937,22 @@ static bsk_status run_basis(int device, const T *knots, int nknots, int order, c
     if (n <= small_call_points()) {
         // small calls (the reference's static Spline.bspline_values is one point): everything travels
         // through one pinned, device-mapped buffer - no allocation, no staging copy, one synchronisation
-        static thread_local void *pin = nullptr;
-        static thread_local size_t pin_cap = 0;
+        // per-thread scratch, returned when the thread ends (found by the AddressSanitizer run of the host
+        // code: the bare thread_local pointers leaked one pinned and one device buffer per calling thread)
+        struct Scratch {
+            void *pin = nullptr;
+            size_t pin_cap = 0;
+            DevBuf dtab;
+            ~Scratch()
+            {
+                if (pin) (void)hipHostFree(pin);
+                dtab.release();
+            }
+        };
+        static thread_local Scratch scratch;
+        void *&pin = scratch.pin;
+        size_t &pin_cap = scratch.pin_cap;
+        DevBuf &dtab_small = scratch.dtab;
         auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
         const size_t o_tab = 0, o_u = o_tab + up(sizeof(T) * tab.size()), o_k = o_u + up(sizeof(T) * (size_t)n);
         const size_t o_ix = o_k + up(sizeof(int) * (size_t)n), o_b = o_ix + up(sizeof(int) * (size_t)n);
@@ -1959,7 +1973,6 @@ static bsk_status run_basis(int device, const T *knots, int nknots, int order, c
         if (knot_in) memcpy(hp + o_k, knot_in, sizeof(int) * (size_t)n);
         // the axis table is read many times with dependent accesses (span search, recursion): it goes to
         // device memory (one small DMA from the pinned buffer); parameters and results stay zero-copy
-        static thread_local DevBuf dtab_small;
         HIPCHK(dtab_small.reserve(sizeof(T) * tab.size()));
         HIPCHK(hipMemcpyAsync(dtab_small.p, hp + o_tab, sizeof(T) * tab.size(), hipMemcpyHostToDevice, 0));
         const int blocks = (int)((n + 255) / 256);

@@ -1,0 +1,10 @@
+// The other translation units of the library, as far as bsk_api.hip's host code links against them: the
+// large-table pipeline declines (its host code is a launch sequence without threads or staging of its own).
+#include "../../bspy_amd/csrc/bsk_host.hpp"
+template <typename T>
+bsk_status gather_or_binned_any(bsk_spline, bool, const Params<T> &, long long, T *, long long, const Wrt &, hipStream_t)
+{
+    return BSK_ERR_UNSUPPORTED;
+}
+template bsk_status gather_or_binned_any<float>(bsk_spline, bool, const Params<float> &, long long, float *, long long, const Wrt &, hipStream_t);
+template bsk_status gather_or_binned_any<double>(bsk_spline, bool, const Params<double> &, long long, double *, long long, const Wrt &, hipStream_t);
