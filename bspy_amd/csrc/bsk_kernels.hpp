@@ -632,6 +632,34 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
     const T *__restrict__ gcoef = pc.c[blockIdx.y];
     T *ppos = pos + (long long)blockIdx.y * 3 * total;
     T *pnrm = NORMALS ? nrm + (long long)blockIdx.y * 3 * total : nullptr;
+    // The columns a lane works on are the same for every grid row of this workgroup: when the row is short
+    // enough (two vector steps per lane) their span indices and basis rows of the second variable are taken
+    // into registers ONCE, and a row then costs LDS reads of the contracted row, multiply-adds and stores only
+    // (before: 21 B of L2 reads per 12 B written).
+    constexpr int HIT = 2;                                       // hoisted vector steps per lane
+    // (positions only: with normals the second basis row per column costs the registers that four waves per
+    // SIMD need - measured 0.78 -> 1.07 ms)
+    const bool hoist = !NORMALS && vec_ok && !MIXED && n1 <= (long long)blockDim.x * VEC * HIT;
+    T hb1[HIT][VEC][O], hdb1[NORMALS ? HIT : 1][NORMALS ? VEC : 1][O];
+    int hix1[HIT][VEC];
+    bool hbad[HIT][VEC];
+    if (hoist) {
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const long long c0 = ((long long)it * blockDim.x + threadIdx.x) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const long long c = c0 + v < n1 ? c0 + v : n1 - 1;
+                hix1[it][v] = ixs[g.goff[1] + c] - O;
+                hbad[it][v] = outside[g.goff[1] + c] != 0;
+#pragma unroll
+                for (int k = 0; k < O; ++k) {
+                    hb1[it][v][k] = rows[g.roff[1] + c * O + k];
+                    if constexpr (NORMALS) hdb1[it][v][k] = drows[g.roff[1] + c * O + k];
+                }
+            }
+        }
+    }
     for (long long i0 = blockIdx.x; i0 < g.n[0]; i0 += gridDim.x) {
         const int ix0 = ixs[g.goff[0] + i0];
         const bool bad0 = outside[g.goff[0] + i0] != 0;
@@ -659,6 +687,50 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
             if constexpr (NORMALS) drowc[e] = dacc;
         }
         __syncthreads();
+        if (hoist) {
+#pragma unroll
+            for (int it = 0; it < HIT; ++it) {
+                const long long c0 = ((long long)it * blockDim.x + threadIdx.x) * VEC;
+                if (c0 < n1) {
+                    T P[3][VEC], Nn[3][VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        if (blockIdx.y == 0 && (bad0 | hbad[it][v])) record_bad(bad, i0 * n1 + c0 + v);
+                        T su[3], sv[3];
+#pragma unroll
+                        for (int dep = 0; dep < 3; ++dep) {
+                            const T *rc = rowc + dep * nc1 + hix1[it][v];
+                            const T *drc = drowc + dep * nc1 + hix1[it][v];
+                            T p = T(0), u_ = T(0), v_ = T(0);
+#pragma unroll
+                            for (int k = 0; k < O; ++k) {
+                                p += rc[k] * hb1[it][v][k];
+                                if constexpr (NORMALS) { u_ += drc[k] * hb1[it][v][k]; v_ += rc[k] * hdb1[it][v][k]; }
+                            }
+                            P[dep][v] = p; su[dep] = u_; sv[dep] = v_;
+                        }
+                        if constexpr (NORMALS) {
+                            T nn[3];
+                            tess_normal<T>(su, sv, normalize, negate, nn);
+                            Nn[0][v] = nn[0]; Nn[1][v] = nn[1]; Nn[2][v] = nn[2];
+                        }
+                    }
+#pragma unroll
+                    for (int dep = 0; dep < 3; ++dep) {
+                        vec_t w;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) w[v] = P[dep][v];
+                        __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(ppos + dep * total + i0 * n1 + c0));
+                        if constexpr (NORMALS) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) w[v] = Nn[dep][v];
+                            __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(pnrm + dep * total + i0 * n1 + c0));
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         const long long step = vec_ok ? VEC : 1;
         for (long long c0 = (long long)threadIdx.x * step; c0 < n1; c0 += (long long)blockDim.x * step) {
             T P[3][VEC], Nn[3][VEC];
