@@ -1138,29 +1138,33 @@ def _uniform_knots(order, ncoef, lo, hi, clamp_lo=True, clamp_hi=True):
     return np.concatenate([left, dom, right])
 
 
-@pytest.mark.parametrize("order,ncoef,dom,clamps", [
-    (4, (64, 64), ((0.0, 1.0), (0.0, 1.0)), (True, True, True, True)),        # cfg2
-    (4, (9, 23), ((-2.0, 3.0), (10.0, 10.5)), (True, True, True, True)),      # shifted / scaled domains, few spans
-    (4, (8, 8), ((0.0, 1.0), (0.0, 1.0)), (True, False, False, True)),        # uniform continuation instead of a clamp
-    (2, (17, 40), ((0.0, 1.0), (-1.0, 1.0)), (True, True, True, True)),       # bilinear
+@pytest.mark.parametrize("order,ncoef,dom,clamps,nDep,dt", [
+    (4, (64, 64), ((0.0, 1.0), (0.0, 1.0)), (True, True, True, True), 3, np.float64),        # cfg2
+    (4, (9, 23), ((-2.0, 3.0), (10.0, 10.5)), (True, True, True, True), 3, np.float64),      # shifted / scaled domains, few spans
+    (4, (8, 8), ((0.0, 1.0), (0.0, 1.0)), (True, False, False, True), 3, np.float64),        # uniform continuation instead of a clamp
+    (2, (17, 40), ((0.0, 1.0), (-1.0, 1.0)), (True, True, True, True), 3, np.float64),       # bilinear
+    (4, (30, 21), ((0.0, 2.0), (0.0, 1.0)), (True, True, True, True), 5, np.float64),        # nDep > 3: dependent-variable-major image
+    (4, (12, 40), ((0.0, 1.0), (0.0, 1.0)), (True, True, True, True), 1, np.float64),        # nDep 1
+    (2, (33, 20), ((0.0, 1.0), (0.0, 4.0)), (True, True, True, True), 2, np.float32),        # fp32 runs this path at order 2 only
 ])
-def test_uniform_knot_path(order, ncoef, dom, clamps, monkeypatch):
+def test_uniform_knot_path(order, ncoef, dom, clamps, nDep, dt, monkeypatch):
     """Equally spaced knots run the table-free kernels (eval_uni / jac_uni) on an unclamped LDS image;
     they must meet the same bar as the general kernels on the same spline (BSK_VARIANT=9): every derivative,
     the fused jacobian and normal, points on every knot and one ulp either side of it (the span rule is
     the reference's searchsorted(..., 'right'): a third derivative tells a wrong side at once)."""
     rng = np.random.default_rng(77)
-    nDep = 3
-    knots = [_uniform_knots(order, nc, lo, hi, clamps[2 * i], clamps[2 * i + 1]) for i, (nc, (lo, hi)) in enumerate(zip(ncoef, dom))]
-    coefs = rng.standard_normal((nDep, *ncoef))
-    t = DeviceSpline((order, order), ncoef, knots, coefs)
+    tol = 1e-12 if dt == np.float64 else 2e-5
+    knots = [_uniform_knots(order, nc, lo, hi, clamps[2 * i], clamps[2 * i + 1]).astype(dt) for i, (nc, (lo, hi)) in enumerate(zip(ncoef, dom))]
+    coefs = rng.standard_normal((nDep, *ncoef)).astype(dt)
+    t = DeviceSpline((order, order), ncoef, knots, coefs, dt)
     n = 20000
-    pts = [lo + (hi - lo) * rng.random(n) for lo, hi in dom]
+    dom = [(float(k[order - 1]), float(k[nc])) for k, nc in zip(knots, ncoef)]
+    pts = [(lo + (hi - lo) * rng.random(n)).astype(dt).clip(dt(lo), dt(hi)) for lo, hi in dom]
     for i, (k, nc) in enumerate(zip(knots, ncoef)):
         kk = np.unique(k[order - 1:nc + 1])
-        edge = np.concatenate([kk, np.nextafter(kk[1:], -np.inf), np.nextafter(kk[:-1], np.inf)])
+        edge = np.concatenate([kk, np.nextafter(kk[1:], dt(-np.inf)), np.nextafter(kk[:-1], dt(np.inf))]).astype(dt)
         pts[i][:edge.size] = edge
-        pts[1 - i][:edge.size] = dom[1 - i][0] + (dom[1 - i][1] - dom[1 - i][0]) * rng.random(edge.size)
+        pts[1 - i][:edge.size] = (dom[1 - i][0] + (dom[1 - i][1] - dom[1 - i][0]) * rng.random(edge.size)).astype(dt).clip(dt(dom[1 - i][0]), dt(dom[1 - i][1]))
     pts[0][-1], pts[1][-1] = dom[0][1], dom[1][1]
     pts[0][-2], pts[1][-2] = dom[0][0], dom[1][0]
     wrts = [(a, b) for a in range(order + 1) for b in range(order + 1) if a + b <= order + 1]
@@ -1169,29 +1173,34 @@ def test_uniform_knot_path(order, ncoef, dom, clamps, monkeypatch):
         assert t.last_kernel() == "eval_uni"
         orc, bad = oracle.c_evaluate((order, order), ncoef, knots, coefs, list(w), pts)
         assert bad == -1
-        assert np.abs(out - orc).max() <= 1e-12 * _scale(orc), (w, np.abs(out - orc).max())
+        assert np.abs(out - orc).max() <= tol * _scale(orc), (w, np.abs(out - orc).max())
     jac = t.jacobian(pts)
     assert t.last_kernel() == "jac_uni"
     orj, _ = oracle.c_jacobian((order, order), ncoef, knots, coefs, pts)
-    assert np.abs(jac - orj).max() <= 1e-12 * _scale(orj)
-    nrm = t.normal(pts)
-    assert t.last_kernel() == "jac_uni"
+    assert np.abs(jac - orj).max() <= tol * _scale(orj)
+    has_normal = abs(2 - nDep) == 1
+    if has_normal:
+        nrm = t.normal(pts)
+        assert t.last_kernel() == "jac_uni"
     # the general kernels on the same spline
     monkeypatch.setenv("BSK_VARIANT", "9")
-    g = DeviceSpline((order, order), ncoef, knots, coefs)
+    g = DeviceSpline((order, order), ncoef, knots, coefs, dt)
     out_g = g.evaluate(pts)
     assert g.last_kernel() == "eval_rowrot"
-    assert np.abs(t.evaluate(pts) - out_g).max() <= 1e-12 * _scale(out_g)
-    assert np.abs(nrm - g.normal(pts)).max() <= 1e-11
+    assert np.abs(t.evaluate(pts) - out_g).max() <= tol * _scale(out_g)
+    if has_normal:
+        gn = g.normal(pts)
+        ok = np.isfinite(gn).all(axis=0)
+        assert np.abs(nrm - gn)[:, ok].max() <= (1e-10 if dt == np.float64 else 1e-3)
     # NaN parameters propagate, out-of-domain points are reported by index
     bad_pts = [p.copy() for p in pts]
     bad_pts[0][123] = np.nan
     assert np.isnan(t.evaluate(bad_pts)[:, 123]).all()
     d3 = t.evaluate(bad_pts, [order - 1, 0])[:, 123]
     o3, _ = oracle.c_evaluate((order, order), ncoef, knots, coefs, [order - 1, 0], [p[123:124] for p in bad_pts])
-    assert np.allclose(d3, o3[:, 0], rtol=1e-12, atol=1e-12, equal_nan=True)
-    bad_pts[0][123] = 0.5 * (dom[0][0] + dom[0][1])
-    bad_pts[1][4567] = np.nextafter(dom[1][1], np.inf)
+    assert np.allclose(d3, o3[:, 0], rtol=100 * tol, atol=100 * tol * _scale(o3), equal_nan=True)
+    bad_pts[0][123] = dt(0.5 * (dom[0][0] + dom[0][1]))
+    bad_pts[1][4567] = np.nextafter(dt(dom[1][1]), dt(np.inf))
     with pytest.raises(bspy_amd.DomainError) as e:
         t.evaluate(bad_pts)
     assert e.value.index == 4567
@@ -1200,7 +1209,7 @@ def test_uniform_knot_path(order, ncoef, dom, clamps, monkeypatch):
     coefs2[:, 0, :] += 1.0
     t.update(knots, coefs2)
     orc2, _ = oracle.c_evaluate((order, order), ncoef, knots, coefs2, [0, 0], pts)
-    assert np.abs(t.evaluate(pts) - orc2).max() <= 1e-12 * _scale(orc2)
+    assert np.abs(t.evaluate(pts) - orc2).max() <= tol * _scale(orc2)
 
 
 @pytest.fixture(scope="module")
