@@ -220,10 +220,11 @@ __host__ __device__ inline int uni_row_stride(int nc1, int nDep, int O)
 // Rank of the lane among the lanes of its half-wave whose windows share banks (classes equal mod
 // 32 / O), requested before the basis is computed and consumed after it (one LDS atomic on a per-wave
 // counter row), and the O row addresses in rotated order.
+// The counters are never reset: lanes that hit one counter in one instruction get CONSECUTIVE values whatever
+// it held, and only the value mod O is used.
 template <int O>
 __device__ __forceinline__ int uni_rank_request(int base, unsigned *s_rc, int lane)
 {
-    s_rc[lane] = 0u;
     return (int)atomicAdd(&s_rc[(lane & 32) + (base & (32 / O - 1))], 1u);
 }
 template <typename T, int O>
