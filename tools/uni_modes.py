@@ -1,7 +1,8 @@
-"""A/B of the eval_uni kernel variants (BSK_UNI_MODE bits: 1 closed-form basis, 2 control-point-major
-image, 4 grouped rotation) on the cfg2 workload: error against the C oracle on 200 k points, then
-steady-state time per 10 M-point launch on random points and on a conflict-free sweep.
-usage: python tools/uni_modes.py 0 1 3 7 [v9]   (v9 = the general kernels, BSK_VARIANT=9)"""
+"""The cfg2 workload on the uniform-knot kernel (argument 0) and on the general kernels (v9 = BSK_VARIANT=9):
+error against the C oracle on 200 k points, then steady-state time per 10 M-point launch on random points
+and on a conflict-free sweep (consecutive lanes in consecutive spans).  During round 2 the arguments selected
+build variants of eval_uni (BSK_UNI_MODE bits, since folded into the one kernel: DESIGN.md section 5.1).
+usage: python tools/uni_modes.py 0 v9 0"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
