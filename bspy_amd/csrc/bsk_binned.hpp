@@ -109,24 +109,29 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const BinPlan
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) M[(size_t)i * bp.chunks + blockIdx.x] = hist[i];
 }
 
-// one workgroup per cell: M[cell][0..chunks) -> exclusive prefix, total[cell]
+// one workgroup per cell: M[cell][0..chunks) -> exclusive prefix, total[cell]; blocks of BIN_MAX_CHUNKS with a carry
 __global__ __launch_bounds__(BIN_MAX_CHUNKS) void bin_rowscan(const int chunks, unsigned *__restrict__ M,
                                                               unsigned *__restrict__ total)
 {
     __shared__ unsigned s[BIN_MAX_CHUNKS];
     unsigned *row = M + (size_t)blockIdx.x * chunks;
     const int t = threadIdx.x;
-    const unsigned v = t < chunks ? row[t] : 0u;
-    s[t] = v;
-    __syncthreads();
-    for (int off = 1; off < BIN_MAX_CHUNKS; off <<= 1) {
-        const unsigned add = t >= off ? s[t - off] : 0u;
+    unsigned carry = 0;
+    for (int c0 = 0; c0 < chunks; c0 += BIN_MAX_CHUNKS) {
+        const unsigned v = c0 + t < chunks ? row[c0 + t] : 0u;
         __syncthreads();
-        s[t] += add;
+        s[t] = v;
         __syncthreads();
+        for (int off = 1; off < BIN_MAX_CHUNKS; off <<= 1) {
+            const unsigned add = t >= off ? s[t - off] : 0u;
+            __syncthreads();
+            s[t] += add;
+            __syncthreads();
+        }
+        if (c0 + t < chunks) row[c0 + t] = carry + s[t] - v;
+        carry += s[BIN_MAX_CHUNKS - 1];
     }
-    if (t < chunks) row[t] = s[t] - v;
-    if (t == BIN_MAX_CHUNKS - 1) total[blockIdx.x] = s[t];
+    if (t == 0) total[blockIdx.x] = carry;
 }
 
 // one workgroup: total[0..cells) -> exclusive prefix in start[]
@@ -186,6 +191,132 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
                 slot[n] = p;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Write-combining forms of the scatter and the un-permute.
+//
+// A random 16-byte access costs the memory system a whole 128-byte line (tools/gather_probe.hip: 47 - 60 G
+// random granules per second whatever the granule size up to a line, from a 20 MB table as from a 160 MB one),
+// and bin_scatter / bin_unpermute issue one per point.  But the records of one (chunk, bin) RUN are
+// contiguous in `rec` / `tmp` by construction (slot = start[bin] + M[bin][chunk] + rank): a workgroup that
+// first orders its chunk by bin in LDS can move every run with neighbouring lanes - a run of 6 records is
+// one or two lines instead of six.  The chunk (<= 8192 points) is sized so that its records fit in LDS.
+//   bin_scatter_wc    counts per bin (LDS atomics, rank kept), scan, records into bin order in LDS,
+//                     slot[n] written (coalesced), then rec[...] run by run; also writes the chunk's
+//                     bin-order tables for the way back: Lb[chunk][bin] (first local position of the bin) and
+//                     pbin[lo + p] (bin of local position p)
+//   bin_unpermute_wc  loads the chunk's runs of `tmp` into LDS the same way, then every point reads its
+//                     result from LDS at Lb[bin] + (slot[n] - run start) and the SoA rows are stored coalesced
+// ---------------------------------------------------------------------------------------------
+constexpr int WC_PPT = 8;             // points per lane of a 1024-lane workgroup: chunk <= 8192
+
+template <typename T, int NIND>
+__global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const Params<T> prm, const long long N,
+                                                       const unsigned short *__restrict__ cell,
+                                                       const unsigned *__restrict__ M, const unsigned *__restrict__ start,
+                                                       BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
+                                                       unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cells = bp.cells;
+    unsigned *lcnt = reinterpret_cast<unsigned *>(smem);
+    unsigned *locb = lcnt + cells;
+    unsigned *next0 = locb + cells;
+    BinRec<T, NIND> *srec = reinterpret_cast<BinRec<T, NIND> *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15));
+    unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
+    const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+    const int cnt = (int)(hi - lo);
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        lcnt[i] = 0u;
+        next0[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
+    }
+    __syncthreads();
+    unsigned ck[WC_PPT], rk[WC_PPT];
+    BinRec<T, NIND> r[WC_PPT];
+#pragma unroll
+    for (int k = 0; k < WC_PPT; ++k) {
+        const int i = k * 1024 + (int)threadIdx.x;
+        const long long nn = lo + (i < cnt ? i : cnt - 1);
+        ck[k] = cell[nn];
+#pragma unroll
+        for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
+    }
+#pragma unroll
+    for (int k = 0; k < WC_PPT; ++k)
+        if (k * 1024 + (int)threadIdx.x < cnt) rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                   // exclusive scan of the bin counts (one wave)
+        const int lane = threadIdx.x;
+        unsigned carry = 0;
+        for (int b0 = 0; b0 < cells; b0 += 64) {
+            const int b = b0 + lane;
+            const unsigned v = b < cells ? lcnt[b] : 0u;
+            unsigned inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (b < cells) locb[b] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WC_PPT; ++k) {
+        const int i = k * 1024 + (int)threadIdx.x;
+        if (i < cnt) {
+            const unsigned p = locb[ck[k]] + rk[k];
+            srec[p] = r[k];
+            sbin[p] = (unsigned short)ck[k];
+            slot[lo + i] = next0[ck[k]] + rk[k];
+        }
+    }
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) Lb[(size_t)blockIdx.x * cells + i] = locb[i];
+    __syncthreads();
+    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+        const unsigned b = sbin[p];
+        rec[next0[b] + ((unsigned)p - locb[b])] = srec[p];
+        pbin[lo + p] = (unsigned short)b;
+    }
+}
+
+template <typename T, int ND>
+__global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const long long N,
+                                                         const unsigned short *__restrict__ cell,
+                                                         const unsigned *__restrict__ slot, const unsigned *__restrict__ M,
+                                                         const unsigned *__restrict__ start, const unsigned *__restrict__ Lb,
+                                                         const unsigned short *__restrict__ pbin,
+                                                         const BinOut<T, ND> *__restrict__ tmp, T *__restrict__ out,
+                                                         const long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cells = bp.cells;
+    unsigned *locb = reinterpret_cast<unsigned *>(smem);
+    unsigned *next0 = locb + cells;
+    BinOut<T, ND> *sout = reinterpret_cast<BinOut<T, ND> *>(smem + ((8 * (size_t)cells + 15) & ~(size_t)15));
+    const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+    const int cnt = (int)(hi - lo);
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        locb[i] = Lb[(size_t)blockIdx.x * cells + i];
+        next0[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+        const unsigned b = pbin[lo + p];
+        sout[p] = tmp[next0[b] + ((unsigned)p - locb[b])];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const long long n = lo + i;
+        const unsigned b = cell[n];
+        const BinOut<T, ND> r = sout[locb[b] + (slot[n] - next0[b])];
+#pragma unroll
+        for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + n], r.v[dd]);
     }
 }
 

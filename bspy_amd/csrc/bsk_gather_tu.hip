@@ -69,6 +69,20 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         static const int env_block = getenv("BSK_BIN_BLOCK") ? atoi(getenv("BSK_BIN_BLOCK")) : 0;
         static const int env_unp = getenv("BSK_UNP_GRID") ? atoi(getenv("BSK_UNP_GRID")) : 0;
         if (env_chunks > 0) bp.chunks = (int)std::min<long long>(std::min(env_chunks, BIN_MAX_CHUNKS), std::max<long long>(1, n / 64));
+        // write-combining scatter / un-permute (bsk_binned.hpp): the chunk's records and results must fit LDS
+        // beside three (two) bin tables; BSK_VARIANT 14 keeps the direct forms
+        const size_t rec_sz = sizeof(BinRec<T, NIND>), out_sz_max = (4 * sizeof(T) + 15) / 16 * 16;
+        long long wc_chunk = 0;
+        if (bp.cells <= 2048 && s->variant != 14 && s->variant != 13) {
+            const size_t room = s->lds_max - 12 * (size_t)bp.cells - 256;
+            wc_chunk = (long long)(room / (std::max(rec_sz, out_sz_max) + 2)) / 1024 * 1024;
+            wc_chunk = std::min<long long>(wc_chunk, 1024 * WC_PPT);
+            static const int env_wc = getenv("BSK_WC_CHUNK") ? atoi(getenv("BSK_WC_CHUNK")) : 0;          // measurement knob
+            if (env_wc > 0) wc_chunk = std::min<long long>(wc_chunk, env_wc);
+            if (wc_chunk < 2048 || (n + wc_chunk - 1) / wc_chunk > 65535) wc_chunk = 0;
+        }
+        const bool wc = wc_chunk > 0;
+        if (wc) bp.chunks = (int)((n + wc_chunk - 1) / wc_chunk);
         const int bin_block = env_block > 0 ? env_block : BIN_BLOCK;
         const int ugrid = env_unp > 0 ? env_unp : 2048;
 
@@ -80,12 +94,14 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_cell = 0, o_slot = o_cell + up(2 * (size_t)n), o_rec = o_slot + up(4 * (size_t)n);
         const size_t o_tmp = o_rec + up(sizeof(BinRec<T, NIND>) * (size_t)n);
-        size_t o_M = 0, o_tot = 0, o_start = 0, total = 0;
+        size_t o_M = 0, o_tot = 0, o_start = 0, o_pbin = 0, o_Lb = 0, total = 0;
         auto layout = [&](size_t out_bytes) {
             o_M = o_tmp + up(out_bytes * (size_t)n);
             o_tot = o_M + up(4 * (size_t)bp.cells * bp.chunks);
             o_start = o_tot + up(4 * (size_t)bp.cells);
-            total = o_start + up(4 * (size_t)bp.cells);
+            o_pbin = o_start + up(4 * (size_t)bp.cells);
+            o_Lb = o_pbin + (wc ? up(2 * (size_t)n) : 0);
+            total = o_Lb + (wc ? up(4 * (size_t)bp.cells * bp.chunks) : 0);
         };
         const T *tab = static_cast<const T *>(s->tab);
         const T *aos = static_cast<const T *>(s->coef_aos);
@@ -125,6 +141,14 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
                            cell, M, s->bad);                                                                             \
         hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
         hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
+        unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
+        unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
+        if (wc) {                                                                                                        \
+            const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
+            HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
+            hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(bp.chunks), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
+                               start, rec, slot, pbin, Lb);                                                              \
+        } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
                            st, bp, prm, n, cell, M, start, rec, slot);                                                   \
         bool cs_done = false;                                                                                            \
@@ -148,6 +172,12 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, MIXED>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d,    \
                            bp, tab, aos, start, rec, n, tmp, w);                                                         \
         }                                                                                                                \
+        if (wc) {                                                                                                        \
+            const size_t lds_u = ((8 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * sizeof(BinOut<T, ND>); \
+            HIPCHK(allow_lds(bin_unpermute_wc<T, ND>, lds_u));                                                           \
+            hipLaunchKernelGGL((bin_unpermute_wc<T, ND>), dim3(bp.chunks), dim3(1024), lds_u, st, bp, n, cell, slot, M,  \
+                               start, Lb, pbin, tmp, out, ostride);                                                      \
+        } else                                                                                                           \
         hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(ugrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
     } break;
         switch (s->nDep) {
