@@ -55,10 +55,11 @@ struct __attribute__((aligned(16))) BinOut {
 };
 
 template <typename T, int O>
-__device__ __forceinline__ int bin_cell(const T *stab, const Desc<T> &d, const BinPlan &bp, T u0, T u1)
+__device__ __forceinline__ int bin_cell(const T *stab, const unsigned *slut, const Desc<T> &d, const TileDesc<T> &td,
+                                        const BinPlan &bp, T u0, T u1)
 {
-    const int i0 = find_span<T>(stab + d.off[0], d.order[0], d.ncoef[0], d.steps[0], u0) - d.order[0];
-    const int i1 = find_span<T>(stab + d.off[1], d.order[1], d.ncoef[1], d.steps[1], u1) - d.order[1];
+    const int i0 = find_span_lut<T>(stab + d.off[0], slut, td, 0, d.lo[0], d.ncoef[0], u0) - d.order[0];
+    const int i1 = find_span_lut<T>(stab + d.off[1], slut, td, 1, d.lo[1], d.ncoef[1], u1) - d.order[1];
     return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
 }
 
@@ -70,15 +71,18 @@ __device__ __forceinline__ int bin_cell(const T *stab, const Desc<T> &d, const B
 constexpr int BIN_ILP = 4;
 
 template <typename T, int NIND, int O>
-__global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+__global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDesc<T> td, const BinPlan bp,
+                                                       const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                        const Params<T> prm, const long long N,
                                                        unsigned short *__restrict__ cell, unsigned *__restrict__ M,
                                                        unsigned long long *bad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *stab = reinterpret_cast<T *>(smem);
-    unsigned *hist = reinterpret_cast<unsigned *>(smem + ((sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15));
+    unsigned *slut = reinterpret_cast<unsigned *>(smem + ((sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15));
+    unsigned *hist = slut + ((td.lut_len + 3) & ~3);
     for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+    for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) slut[i] = glut[i];
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
     const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const BinPlan
 #pragma unroll
                 for (int iv = 0; iv < NIND; ++iv) outside |= (u[k][iv] < d.lo[iv]) | (u[k][iv] > d.hi[iv]);
                 if (outside) record_bad(bad, n);
-                const int c = bin_cell<T, O>(stab, d, bp, u[k][0], u[k][1]);
+                const int c = bin_cell<T, O>(stab, slut, d, td, bp, u[k][0], u[k][1]);
                 cell[n] = (unsigned short)c;
                 atomicAdd(&hist[c], 1u);
             }
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                 const int idx = i * 256 + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
+                    // (the bucket-table search that speeds bin_count up made THIS kernel slower, 297 -> 338 us: not used)
                     key[i] = find_span<T>(tab2, d.order[2], ncl, d.steps[2], rc[i].v[2]) - d.order[2];
                     rank[i] = atomicAdd(&hist[key[i]], 1u);
                 }
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                     BinOut<T, ND> o;
 #pragma unroll
                     for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);
-                    tmp[t0 + idx] = o;
+                    tmp[t0 + idx] = o;        // (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
                 }
             }
         }

@@ -88,7 +88,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
 
         bp.chunk = (n + bp.chunks - 1) / bp.chunks;
         const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
-        const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)bp.cells;
+        const TileDesc<T> &td = tile_of<T>(s);
+        const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)(bp.cells + ((td.lut_len + 3) & ~3));
         if (lds_count > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
 
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -137,8 +138,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
         s->last_kernel = "cell-order pipeline (eval_binned_lds)";                                                        \
-        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, bp, tab, prm, n, \
-                           cell, M, s->bad);                                                                             \
+        hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, td, bp, tab,     \
+                           s->lut, prm, n, cell, M, s->bad);                                                             \
         hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
         hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
         unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \

@@ -129,6 +129,27 @@ struct TileDesc {
     unsigned tab_bytes, lut_bytes, coef_bytes;   // rounded up to 16
 };
 
+// Span search through the bucket table of variable iv (same result as find_span): one table read brackets the
+// span, `lut_steps` bisection steps on the knots finish it (1 for near-uniform knots, against ceil(log2(spans)))
+template <typename T, typename KP, typename LP>
+__device__ __forceinline__ int find_span_lut(KP knots, LP lut, const TileDesc<T> &td, int iv, T lo, int ncoef, T u)
+{
+    int b = (int)((u - lo) * td.lut_scale[iv]);
+    b = min(max(b, 0), td.lut_m[iv] - 1);
+    const unsigned e = lut[td.lut_off[iv] + b];
+    int l = (int)(e & 0xffffu), h = (int)(e >> 16);
+    for (int s = 0; s < td.lut_steps[iv]; ++s) {
+        const int mid = (l + h) >> 1;
+        const T km = knots[mid];
+        const bool open = l < h;
+        const bool right = open && (km <= u);
+        const bool left = open && !right;
+        l = right ? mid + 1 : l;
+        h = left ? mid : h;
+    }
+    return (u != u) ? ncoef : l;
+}
+
 // Descriptor of the uniform-knot surface kernels (bsk_uniform.hpp): domain, span width, image layout.
 template <typename T>
 struct UniDesc {
