@@ -552,6 +552,30 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
     assert e.value.index == 123_456
 
 
+@pytest.mark.parametrize("variant,kernel", [("0", "eval_cellsort, MFMA"), ("12", "eval_cellsort, VALU"), ("13", "eval_binned_lds"),
+                                            ("14", "eval_cellsort, MFMA"), ("7", "eval_gather")])
+def test_cell_order_pipeline_variants(variant, kernel, monkeypatch):
+    """Every form of the large-table path on the cfg5 shape (three variables, order 5, 40^3 x 4, fp32) against the
+    oracle: MFMA and VALU contraction of eval_cellsort, round 1's eval_binned_lds, the direct (14) instead of the
+    write-combining scatter / un-permute, and the gather kernel in batch order (7)."""
+    monkeypatch.setenv("BSK_VARIANT", variant)
+    nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    rng = np.random.default_rng(int(variant) + 1)
+    n = 400_003
+    pts = [rng.random(n).astype(dt) for _ in range(3)]
+    pts[2][:1000] = dt(1.0)                                  # right end of the domain, and a crowded cell
+    pts[0][1000:2000] = dt(0.0)
+    sample = rng.choice(n, 30_000, replace=False)
+    sample[:50] = np.arange(50)
+    for w in ([0, 0, 0], [1, 0, 2]):
+        out = t.evaluate(pts, w)
+        assert kernel in t.last_kernel(), t.last_kernel()
+        orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, [p[sample] for p in pts])
+        assert bad == -1
+        assert np.abs(out[:, sample] - orc).max() <= 2e-5 * _scale(orc), (variant, w)
+
+
 @pytest.mark.parametrize("shape", [
     (1, 3, (4,), (50_000,), np.float64),          # 1.2 MB curve table
     (2, 2, (4, 4), (200, 150), np.float64),       # 480 KB surface table
