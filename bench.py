@@ -323,9 +323,10 @@ def main():
             for _ in range(k):
                 step()
             evs[1].record()
-        barrier()
+        torch.cuda.synchronize()            # this rank's K steps are done: its clock stops here ...
         t1 = time.perf_counter()
-        elapsed = t1 - t0
+        barrier()                           # ... every rank's are; the MAX over ranks below is the job's time (the
+        elapsed = t1 - t0                   # closing barrier's own ~50 us of RCCL latency is not part of the K steps)
         kernel_ms = evs[0].elapsed_time(evs[-1]) / k
         median_ms = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(k)) if per_launch else None
         if dist is not None:
