@@ -326,7 +326,9 @@ def main():
         torch.cuda.synchronize()            # this rank's K steps are done: its clock stops here ...
         t1 = time.perf_counter()
         barrier()                           # ... every rank's are; the MAX over ranks below is the job's time (the
-        elapsed = t1 - t0                   # closing barrier's own ~50 us of RCCL latency is not part of the K steps)
+        t2 = time.perf_counter()            # closing barrier's own ~50 us of RCCL latency is not part of the K steps;
+        elapsed = t1 - t0                   # the figure that includes it is reported beside it for N > 1)
+        measure.incl_barrier = t2 - t0
         kernel_ms = evs[0].elapsed_time(evs[-1]) / k
         median_ms = statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(k)) if per_launch else None
         if dist is not None:
@@ -345,6 +347,7 @@ def main():
     elapsed, kernel_ms, median_ms = measure(step, per_launch=(world == 1 and n_local >= 5_000_000))
     tables.domain_status()                                # the in-kernel domain check found nothing
     kernel = tables.last_kernel()
+    incl_barrier = measure.incl_barrier
 
     extra = {}
     if dist is not None:
@@ -391,6 +394,8 @@ def main():
                          "kernel_ms_median": round(median_ms, 5) if median_ms is not None else None,
                          "algorithmic_bytes_per_eval": bpe, "algorithmic_bytes_per_launch": bpe * n_local},
         }
+        if dist is not None:
+            res["ms_per_step_incl_closing_barrier"] = round(incl_barrier / args.steps * 1e3, 5)
         res.update(extra)
         if world == 1:
             res["roofline"]["measured_stream_floor_GBs"] = stream_floor(torch, tables, u, v, n_local)
