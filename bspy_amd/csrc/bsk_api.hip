@@ -473,8 +473,12 @@ static bool rowrot_applies(bsk_spline s)
 // ------------------------------------------------------------------------------------
 // uniform-knot surface path (bsk_uniform.hpp): detection, unclamping, LDS image
 // ------------------------------------------------------------------------------------
-// Domain knots equally spaced (within 4 ulp of the larger domain end), each end either clamped (order
-// equal knots) or continuing the uniform spacing.
+// Domain knots equally spaced, each end either clamped (order equal knots) or continuing the uniform spacing.
+// "Equally" is relative to the SPAN: the kernels take the local coordinate from the stored knot and the nominal
+// span width h, the reference from the stored knots alone, so a knot that sits d away from lo + j h moves the
+// result by ~d / h.  Accepted: d <= 1024 ulp of h in fp64 (2e-13 h: linspace knots of a domain near the origin
+// are 10 - 100 times closer), 32 ulp in fp32.  Equally spaced knots far from the origin relative to their
+// spacing (lo = 1e6, h = 1e-3: d / h ~ 1e-7) are therefore NOT taken by this path.
 template <typename T>
 static bool axis_is_uniform(const T *k, int order, int ncoef, bool &clamp_lo, bool &clamp_hi)
 {
@@ -482,7 +486,7 @@ static bool axis_is_uniform(const T *k, int order, int ncoef, bool &clamp_lo, bo
     const long double lo = k[order - 1], hi = k[ncoef];
     if (!(hi > lo) || ns < 1) return false;
     const long double h = (hi - lo) / ns;
-    const long double tol = 4.0L * std::numeric_limits<T>::epsilon() * std::max(std::fabs(lo), std::fabs(hi));
+    const long double tol = (sizeof(T) == 8 ? 1024.0L : 32.0L) * std::numeric_limits<T>::epsilon() * h;
     for (int j = 0; j <= ns; ++j)
         if (std::fabs((long double)k[order - 1 + j] - (lo + j * h)) > tol) return false;
     auto side = [&](bool low, bool &clamped) {

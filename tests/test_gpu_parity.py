@@ -1318,3 +1318,22 @@ def test_ufunc_keyword_arguments(golden_extras):
     assert np.array_equal(np.stack(fouts), np.stack(surf.derivative([1, 0], u, v)))
     with pytest.raises(TypeError):
         surf(u, v, casting="unsafe")
+
+
+def test_uniform_path_declines_knots_far_from_the_origin():
+    """Equally spaced knots whose rounding is large against their spacing (lo = 1e6, h = 1e-3: the stored knots are
+    1e-7 spans away from lo + j h) must not take the table-free kernels: the reference works from the STORED knots."""
+    rng = np.random.default_rng(5)
+    order, ncoef = 4, (24, 24)
+    knots = [_uniform_knots(order, nc, 1.0e6, 1.0e6 + 0.021) for nc in ncoef]
+    coefs = rng.standard_normal((3, *ncoef))
+    t = DeviceSpline((order, order), ncoef, knots, coefs)
+    pts = [rng.uniform(k[order - 1], k[nc], 5000) for k, nc in zip(knots, ncoef)]
+    for w in ([0, 0], [2, 1]):
+        out = t.evaluate(pts, w)
+        assert t.last_kernel() == "eval_rowrot"
+        orc, bad = oracle.c_evaluate((order, order), ncoef, knots, coefs, w, pts)
+        assert bad == -1 and np.abs(out - orc).max() <= 1e-12 * _scale(orc)
+    near = DeviceSpline((order, order), ncoef, [_uniform_knots(order, nc, 10.0, 10.5) for nc in ncoef], coefs)
+    near.evaluate([rng.uniform(10.0, 10.5, 100), rng.uniform(10.0, 10.5, 100)])
+    assert near.last_kernel() == "eval_uni"
