@@ -63,6 +63,21 @@ __device__ __forceinline__ int bin_cell(const T *stab, const unsigned *slut, con
     return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
 }
 
+// Span of the third variable (the key of eval_cellsort's second grouping), found by the scatter kernels - they
+// wait for HBM and have the issue slots - through the bucket table and the knots in global memory (two dependent
+// L1 hits), and carried in the record's spare word.  (In bin_count the same search cost 23 us, in eval_cellsort
+// the bisection was ~85 of its ~360 vector instructions per point.)
+template <typename T, int NIND>
+__device__ __forceinline__ void rec_key(BinRec<T, NIND> &r, const Desc<T> &d, const TileDesc<T> &td, const T *__restrict__ gtab,
+                                        const unsigned *__restrict__ glut)
+{
+    if constexpr (NIND == 3) {
+        using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+        const int key = find_span_lut<T>(gtab + d.off[2], glut, td, 2, d.lo[2], d.ncoef[2], r.v[2]) - d.order[2];
+        r.v[3] = __builtin_bit_cast(T, (Tag)(unsigned)key);
+    }
+}
+
 // LDS: [axis tables][cells x u32]
 // Four independent points per lane and iteration (loads, span searches and histogram updates of the four
 // interleave: a single chain per lane is bound by its dependent LDS / HBM round trips).
@@ -166,7 +181,9 @@ template <typename T, int NIND>
 __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Params<T> prm, const long long N,
                                                          const unsigned short *__restrict__ cell,
                                                          const unsigned *__restrict__ M, const unsigned *__restrict__ start,
-                                                         BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot)
+                                                         BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
+                                                         const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
+                                                         const unsigned *__restrict__ glut, const int keyed)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *next = reinterpret_cast<unsigned *>(smem);
@@ -185,6 +202,10 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
             for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
 #pragma unroll
             for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
+        }
+        if (keyed) {
+#pragma unroll
+            for (int k = 0; k < BIN_ILP; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
         }
 #pragma unroll
         for (int k = 0; k < BIN_ILP; ++k) {
@@ -221,7 +242,9 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                                                        const unsigned short *__restrict__ cell,
                                                        const unsigned *__restrict__ M, const unsigned *__restrict__ start,
                                                        BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
-                                                       unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb)
+                                                       unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb,
+                                                       const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
+                                                       const unsigned *__restrict__ glut, const int keyed)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cells = bp.cells;
@@ -252,6 +275,10 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
 #pragma unroll
     for (int k = 0; k < WC_PPT; ++k)
         if (k * 1024 + (int)threadIdx.x < cnt) rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
+    if (keyed) {
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {                                   // exclusive scan of the bin counts (one wave)
         const int lane = threadIdx.x;
@@ -497,8 +524,171 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
 // ---------------------------------------------------------------------------------------------
 constexpr int CS_TILE = 1024;           // records sorted at a time (4 per lane of a 256-lane workgroup)
 constexpr int CS_MAX_S2 = 256;          // spans of the third variable the LDS histogram holds
+constexpr int CS_AHEAD = 4;             // rows of coefficient reads in flight ahead of the MFMAs that use them
 
 typedef float cs_f4 __attribute__((ext_vector_type(4)));
+
+// Table values of one span for the Cox-de Boor recursion: kn[j] = knots[ix - (O - 1) + j] (j < O - 1) and
+// rc[D][j] = r_D[ix - D + j] (j < D) - the entries basis_fixed reads, fetched together.
+template <typename T, int O>
+struct SpanTab {
+    T kn[O > 1 ? O - 1 : 1];
+    T rc[O][O];
+};
+
+// basis_fixed's recursion (same operations in the same order: same bits) on a SpanTab
+template <typename T, int O>
+__device__ __forceinline__ void basis_regs(const SpanTab<T, O> &t, T u, int wrt, T (&b)[O])
+{
+#pragma unroll
+    for (int k = 0; k < O; ++k) b[k] = T(0);
+    if (wrt >= O) return;
+    b[O - 1] = T(1);
+#pragma unroll
+    for (int degree = 1; degree < O; ++degree) {
+        if (degree < O - wrt) {
+#pragma unroll
+            for (int j = 0; j < degree; ++j) {
+                const int bi = O - degree + j;
+                const T alpha = (u - t.kn[(O - 1) - degree + j]) * t.rc[degree][j];
+                b[bi - 1] += (T(1) - alpha) * b[bi];
+                b[bi] *= alpha;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < degree; ++j) {
+                const int bi = O - degree + j;
+                const T alpha = T(degree) * t.rc[degree][j];
+                b[bi - 1] -= alpha * b[bi];
+                b[bi] *= alpha;
+            }
+        }
+    }
+}
+
+// wave-uniform value -> scalar register (fp32; wider types stay in vector registers)
+template <typename T>
+__device__ __forceinline__ T cs_uniform(T x)
+{
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+    else return x;
+}
+
+// The span's table values of a variable whose span is the same for the whole workgroup (the bin's first two
+// variables): read once per bin, kept in scalar registers.
+template <typename T, int O>
+__device__ __forceinline__ void span_tab_uniform(const T *tab, int nk, int ix, SpanTab<T, O> &t)
+{
+#pragma unroll
+    for (int j = 0; j < O - 1; ++j) t.kn[j] = cs_uniform(tab[ix - (O - 1) + j]);
+#pragma unroll
+    for (int D = 1; D < O; ++D)
+#pragma unroll
+        for (int j = 0; j < D; ++j) t.rc[D][j] = cs_uniform(tab[D * nk + ix - D + j]);
+}
+
+// All table reads of a lane's own span in flight together (explicit reads: hipcc otherwise fetches every level of
+// the recursion right before it and waits for each); span_tab_wait completes them.
+template <typename T, int O>
+__device__ __forceinline__ void span_tab_issue(unsigned tab_addr, int nk, int ix, SpanTab<T, O> &t)
+{
+    if constexpr (O > 1) {
+        lds_issue_n<T, O - 1, (O > 1 ? O - 1 : 1)>(tab_addr + (unsigned)(ix - (O - 1)) * (unsigned)sizeof(T), t.kn);
+        basis_issue<T, O, 1>(tab_addr, nk, ix, t.rc);
+    }
+}
+template <typename T, int O>
+__device__ __forceinline__ void span_tab_wait(SpanTab<T, O> &t)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < O - 1; ++j) asm volatile("" : "+v"(t.kn[j]) :: "memory");
+#pragma unroll
+    for (int D = 1; D < O; ++D)
+#pragma unroll
+        for (int j = 0; j < D; ++j) asm volatile("" : "+v"(t.rc[D][j]) :: "memory");
+}
+
+// The contraction of eval_cellsort<..., MFMA>: explicit LDS reads, issued CS_AHEAD rows before the instructions that
+// use them (left to itself hipcc loads every row into the same registers right before its first use and waits for
+// each; __builtin_amdgcn_sched_group_barrier did not change that).  hipcc does not track asm operands: the value of
+// a read is tied to the wait that completes it, and check_lds_hazards.py replays the assembly (Makefile).
+template <int OFF>
+__device__ __forceinline__ cs_f4 cs_lds_b128(unsigned addr)
+{
+    cs_f4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <int O>
+struct CsRow {                                              // the coefficient operands of one window row
+    static constexpr int G = O / 4, R = O % 4;
+    cs_f4 g[G > 0 ? G : 1];
+    float r[R > 0 ? R : 1];
+};
+
+template <int O, int ROW>
+__device__ __forceinline__ void cs_issue_row(unsigned a_addr, unsigned r_addr, CsRow<O> &row)
+{
+    constexpr int ROWS = O * O, G = O / 4, R = O % 4;
+    static_assert(G <= 1 && ((G * 4 + R) * ROWS) * 16 < 65536, "offsets of the row reads");
+    if constexpr (G >= 1) row.g[0] = cs_lds_b128<ROW * 16>(a_addr);
+    if constexpr (R >= 1) row.r[0] = LdsRead<float>::template at<(0 * ROWS + ROW) * 16>(r_addr);
+    if constexpr (R >= 2) row.r[1] = LdsRead<float>::template at<(1 * ROWS + ROW) * 16>(r_addr);
+    if constexpr (R >= 3) row.r[2] = LdsRead<float>::template at<(2 * ROWS + ROW) * 16>(r_addr);
+}
+
+// wait until at most CNT younger reads are outstanding; the row's values become available here
+template <int O, int CNT>
+__device__ __forceinline__ void cs_wait_row(CsRow<O> &row)
+{
+    constexpr int G = O / 4, R = O % 4;
+    static_assert(CNT >= 0 && CNT <= 15, "lgkmcnt is 4 bits");
+    if constexpr (G == 1 && R == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(row.g[0]) : "n"(CNT) : "memory");
+    else if constexpr (G == 1 && R == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(row.g[0]), "+v"(row.r[0]) : "n"(CNT) : "memory");
+    else if constexpr (G == 1 && R == 2)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(row.g[0]), "+v"(row.r[0]), "+v"(row.r[1]) : "n"(CNT) : "memory");
+    else if constexpr (G == 0 && R == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(row.r[0]) : "n"(CNT) : "memory");
+    else if constexpr (G == 0 && R == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(row.r[0]), "+v"(row.r[1]) : "n"(CNT) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(row.r[0]), "+v"(row.r[1]), "+v"(row.r[2]) : "n"(CNT) : "memory");
+}
+
+template <int O, int ND, int ROW>
+__device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O],
+                                        CsRow<O> (&buf)[CS_AHEAD + 1], cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1],
+                                        cs_f4 (&accr)[(O % 4) > 0 ? (O % 4) : 1])
+{
+    constexpr int ROWS = O * O, G = O / 4, R = O % 4, NS = CS_AHEAD + 1;
+    if constexpr (ROW < ROWS) {
+        if constexpr (ROW + CS_AHEAD < ROWS) cs_issue_row<O, ROW + CS_AHEAD>(a_addr, r_addr, buf[(ROW + CS_AHEAD) % NS]);
+        constexpr int later = ROWS - 1 - ROW < CS_AHEAD ? ROWS - 1 - ROW : CS_AHEAD;
+        CsRow<O> &row = buf[ROW % NS];
+        cs_wait_row<O, (G + R) * later>(row);
+        const float wgt = b0[ROW / O] * b1[ROW % O];
+        if constexpr (G >= 1) {
+#pragma unroll
+            for (int dd = 0; dd < ND; ++dd) accg[dd] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.g[0][dd], wgt, accg[dd], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < R; ++r2) accr[r2] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.r[r2], wgt, accr[r2], 0, 0, 0);
+        cs_rows<O, ND, ROW + 1>(a_addr, r_addr, b0, b1, buf, accg, accr);
+    }
+}
+
+template <int O, int ND>
+__device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O],
+                                            cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1], cs_f4 (&accr)[(O % 4) > 0 ? (O % 4) : 1])
+{
+    CsRow<O> buf[CS_AHEAD + 1];
+    constexpr int ROWS = O * O;
+    if constexpr (ROWS > 0 && CS_AHEAD > 0) cs_issue_row<O, 0>(a_addr, r_addr, buf[0]);
+    if constexpr (ROWS > 1 && CS_AHEAD > 1) cs_issue_row<O, 1>(a_addr, r_addr, buf[1]);
+    if constexpr (ROWS > 2 && CS_AHEAD > 2) cs_issue_row<O, 2>(a_addr, r_addr, buf[2]);
+    if constexpr (ROWS > 3 && CS_AHEAD > 3) cs_issue_row<O, 3>(a_addr, r_addr, buf[3]);
+    static_assert(CS_AHEAD <= 4, "prologue");
+    cs_rows<O, ND, 0>(a_addr, r_addr, b0, b1, buf, accg, accr);
+}
 
 template <typename T, int O, int ND, bool MFMA>
 __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
@@ -542,23 +732,24 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
         const long long sl = cb > lo ? cb : lo, sh = ce < hi ? ce : hi;
         if (sl >= sh) continue;
         const int q0 = c / bp.n1, q1 = c % bp.n1;          // window starts of the first two variables (bins are exact spans)
+        SpanTab<T, O> st0, st1;                              // their table values: the same for every point of the bin
+        span_tab_uniform<T, O>(stab + d.off[0], d.nk[0], q0 + O, st0);
+        span_tab_uniform<T, O>(stab + d.off[1], d.nk[1], q1 + O, st1);
         __syncthreads();                                     // previous bin's readers are done
         // bundle: row r = (i, j) of the bin's O x O control-point rows along the third variable
         for (int r = wave; r < ROWS; r += 4) {
             const int i = r / O, j = r - i * O;
             const T *__restrict__ src = aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1) * ND;
             if constexpr (MFMA) {
-                // [row][dep][k], dependent variables beyond ND zero
+                // [k][row][4]: the rows of one control-point index k of the third variable side by side, so that a
+                // lane's window rows sit at compile-time offsets from ONE address; dependent variables beyond ND zero
                 if constexpr (ND == 4) {
-                    for (int k = lane; k < ncl; k += 64) {
-                        const float4 q = *reinterpret_cast<const float4 *>(src + 4 * k);       // one control point
-                        T *dst = bun + (size_t)r * 4 * ncl + k;
-                        dst[0] = q.x; dst[ncl] = q.y; dst[2 * ncl] = q.z; dst[3 * ncl] = q.w;
-                    }
+                    for (int k = lane; k < ncl; k += 64)
+                        *reinterpret_cast<float4 *>(bun + ((size_t)k * ROWS + r) * 4) = *reinterpret_cast<const float4 *>(src + 4 * k);
                 } else {
                     for (int e = lane; e < 4 * ncl; e += 64) {
-                        const int dep = e / ncl, k = e - dep * ncl;
-                        bun[(size_t)r * 4 * ncl + e] = dep < ND ? src[k * ND + dep] : T(0);
+                        const int k = e >> 2, dep = e & 3;
+                        bun[((size_t)k * ROWS + r) * 4 + dep] = dep < ND ? src[k * ND + dep] : T(0);
                     }
                 }
             } else {
@@ -586,8 +777,7 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                 const int idx = i * 256 + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
-                    // (the bucket-table search that speeds bin_count up made THIS kernel slower, 297 -> 338 us: not used)
-                    key[i] = find_span<T>(tab2, d.order[2], ncl, d.steps[2], rc[i].v[2]) - d.order[2];
+                    key[i] = (int)(unsigned)__builtin_bit_cast(Tag, rc[i].v[3]);      // found by the scatter kernel (rec_key)
                     rank[i] = atomicAdd(&hist[key[i]], 1u);
                 }
             }
@@ -652,36 +842,44 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                 const int ix2 = (int)(tag >> 16);
                 const unsigned idx = tag & 0xffffu;
                 T b[3][O];
-                basis_fixed<T, O>(stab + d.off[0], d.nk[0], q0 + O, r.v[0], wrt.w[0], b[0]);
-                basis_fixed<T, O>(stab + d.off[1], d.nk[1], q1 + O, r.v[1], wrt.w[1], b[1]);
-                basis_fixed<T, O>(tab2, d.nk[2], ix2 + O, r.v[2], wrt.w[2], b[2]);
+                SpanTab<T, O> st2;
+                span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
+                basis_regs<T, O>(st0, r.v[0], wrt.w[0], b[0]);
+                basis_regs<T, O>(st1, r.v[1], wrt.w[1], b[1]);
+                span_tab_wait<T, O>(st2);
+                basis_regs<T, O>(st2, r.v[2], wrt.w[2], b[2]);
                 T res[ND];
                 if constexpr (MFMA) {
-                    cs_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                    const T *arow = bun + (size_t)(lane & 3) * ncl + ix2;
-                    T w12[O][O];
+                    // The steps m of the THIRD variable go four at a time into the ROWS of the outer product:
+                    //   group g, dependent variable dd:  D[m'][point] += C[i][j][4g + m'][dd] * (b0_i b1_j)[point]
+                    //   remaining step m = 4G + r:       D[dd][point] += C[i][j][m][dd]      * (b0_i b1_j)[point]
+                    // Lane l = 4 b + m' of block b feeds control point ix2 + 4g + m' of its block's cell: ALL its dependent
+                    // variables are one aligned 16-byte LDS read (ds_read_b128: 256 B/clk, a 4-byte read 128 B/clk and
+                    // a misaligned wide read less - tools/lds_unaligned_probe.hip), used by the ND instructions of the
+                    // group; a remaining step reads 4 bytes.  O = 5, ND = 4: 5 MFMAs and 6 LDS cycles per row (was 10);
+                    // ND < 4 needs ND instead of 4 instructions per group.  The B operand is the row weight alone (O^2
+                    // products per point instead of O^3), the chains are independent, and the lane combines its own
+                    // sums with b2 at the end.
+                    constexpr int G = O / 4, R = O % 4;
+                    cs_f4 accg[G > 0 ? G * ND : 1], accr[R > 0 ? R : 1];
 #pragma unroll
-                    for (int j = 0; j < O; ++j)
+                    for (int q2 = 0; q2 < G * ND; ++q2) accg[q2] = cs_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int m = 0; m < O; ++m) w12[j][m] = b[1][j] * b[2][m];
-// (Forming the O x O weights of a slab first and issuing its MFMAs back to back - no wait states between a
-                    // product and the MFMA that reads it - needs 64 more registers and measured 4 % slower.)
+                    for (int q2 = 0; q2 < R; ++q2) accr[q2] = cs_f4{0.f, 0.f, 0.f, 0.f};
+                    const unsigned a_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + (lane & 3)) * (ROWS * 16));
+                    const unsigned r_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + 4 * G) * (ROWS * 16) + (lane & 3) * 4);
+                    cs_contract<O, ND>(a_addr, r_addr, b[0], b[1], accg, accr);
 #pragma unroll
-                    for (int i = 0; i < O; ++i) {
+                    for (int dd = 0; dd < ND; ++dd) {
+                        T sum = T(0);
 #pragma unroll
-                        for (int j = 0; j < O; ++j) {
-                            const T *ap = arow + (size_t)(i * O + j) * 4 * ncl;
+                        for (int g2 = 0; g2 < G; ++g2)
 #pragma unroll
-                            for (int m = 0; m < O; ++m) {
-                                const float a = ap[m];
-                                const float wgt = b[0][i] * w12[j][m];
-                                if (((i * O + j) * O + m) & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, wgt, acc1, 0, 0, 0);
-                                else acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, wgt, acc0, 0, 0, 0);
-                            }
-                        }
+                            for (int m = 0; m < 4; ++m) sum += b[2][4 * g2 + m] * accg[g2 * ND + dd][m];
+#pragma unroll
+                        for (int r2 = 0; r2 < R; ++r2) sum += b[2][4 * G + r2] * accr[r2][dd];
+                        res[dd] = sum;
                     }
-#pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) res[dd] = acc0[dd] + acc1[dd];
                 } else {
                     int pad[3] = {0, 0, 0};
                     window_contract<T, 3, O, ND, false>(bun + (long long)ix2 * ND, O * ncl, ncl, pad, b, res);

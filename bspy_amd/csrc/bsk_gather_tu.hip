@@ -148,10 +148,10 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(bp.chunks), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
-                               start, rec, slot, pbin, Lb);                                                              \
+                               start, rec, slot, pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, start, rec, slot);                                                   \
+                           st, bp, prm, n, cell, M, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0);             \
         bool cs_done = false;                                                                                            \
         if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
             cs_done = true;                                                                                              \

@@ -165,4 +165,16 @@ struct UniDesc {
     unsigned img_bytes;    // multiple of 16
 };
 
+// The same for curves, surfaces of other orders and volumes (eval_stream_uni / jac_stream_uni).
+template <typename T>
+struct UniDescN {
+    T lo[3], hi[3];
+    T inv_h[3];
+    T eps;
+    int ns[3];
+    unsigned kn_off[3];    // byte offsets inside the image
+    unsigned coef_off;
+    unsigned img_bytes;    // multiple of 16
+};
+
 }  // namespace bsk

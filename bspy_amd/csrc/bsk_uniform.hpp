@@ -447,4 +447,221 @@ __global__ __launch_bounds__(TILE) void jac_uni(const UniDesc<T> ud, const void 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same table-free front end for the other LDS-resident shapes: curves, surfaces of order 3 / 5,
+// volumes - eval_stream / jac_stream (bsk_stream.hpp) with `uni_spans` + `uni_basis` in place of the
+// bucket-table search and the knot / reciprocal rows.  Image: [domain knots of every variable]
+// [unclamped coefficients in the reference's (nDep, nCoef...) layout].  fp64 only (order <= 2: also
+// fp32), and only while the unclamping factors of the variables multiply to <= 5000 (host:
+// upload_uniform_nd), i.e. not for three variables of order 5.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NIND, bool NANFIX>
+__device__ __forceinline__ void uni_spans(unsigned img_a, const UniDescN<T> &un, const T (&u)[NIND], int (&m)[NIND], T (&z)[NIND])
+{
+    int m0[NIND];
+    T t1[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) {
+        const T x = (u[iv] - un.lo[iv]) * un.inv_h[iv] - un.eps;
+        m0[iv] = min(max((int)x, 0), un.ns[iv] - 1);
+        t1[iv] = LdsRead<T>::template at<(int)sizeof(T)>(img_a + un.kn_off[iv] + (unsigned)m0[iv] * (unsigned)sizeof(T));
+    }
+    lds_wait_n<0, NIND>(t1);
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) {
+        const bool inc = (u[iv] >= t1[iv]) & (m0[iv] < un.ns[iv] - 1);
+        m[iv] = m0[iv] + (inc ? 1 : 0);
+        z[iv] = (u[iv] - t1[iv]) * un.inv_h[iv] + (inc ? T(0) : T(1));
+        if (NANFIX && u[iv] != u[iv]) m[iv] = un.ns[iv] - 1;
+    }
+}
+
+template <typename T, int NIND, int O, bool DERIV>
+__global__ __launch_bounds__(STREAM_BLOCK) void eval_stream_uni(const Desc<T> d, const UniDescN<T> un, const void *__restrict__ gimg,
+                                                                const Params<T> prm, const long long N, T *__restrict__ out,
+                                                                const long long ostride, const Wrt wrt, unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned img_a = (unsigned)(size_t)smem;
+    const unsigned coef_a = img_a + un.coef_off;
+    stage_linear(smem, gimg, un.img_bytes);
+    __syncthreads();
+    const unsigned dstride = (unsigned)d.cstride[0] * (unsigned)sizeof(T);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    T lo_r[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) lo_r[iv] = un.lo[iv];
+    T unx[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) {
+        unx[iv] = lo_r[iv];
+        if (n < N) unx[iv] = prm.p[iv][n];
+    }
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(unx[iv]));   // see eval_stream: no load pending at the loop header
+
+    for (; n < N; n += stride) {
+        T u[NIND];
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            u[iv] = unx[iv];
+            outside |= (u[iv] < lo_r[iv]) | (u[iv] > un.hi[iv]);
+            unx[iv] = lo_r[iv];
+        }
+        if (n + stride < N) {
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) unx[iv] = prm.p[iv][n + stride];
+        }
+        if (outside) record_bad(bad, n);
+
+        int m[NIND];
+        T z[NIND];
+        uni_spans<T, NIND, DERIV>(img_a, un, u, m, z);
+        T b[NIND][O];
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) uni_basis<T, O, DERIV>(z[iv], DERIV ? wrt.w[iv] : 0, un.inv_h[iv], b[iv]);
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(unx[iv]));   // prefetched parameters, before the stores
+        unsigned caddr = coef_a;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)(m[iv] * d.cstride[iv + 1]) * (unsigned)sizeof(T);
+
+        if constexpr (NIND <= 2) {
+            constexpr int R = NIND == 1 ? 1 : O;
+            const unsigned rstride = NIND == 1 ? 0u : (unsigned)d.cstride[1] * (unsigned)sizeof(T);
+            for (int dep = 0; dep < d.nDep; ++dep) {
+                T c[R][O];
+                block_issue<T, R, O>(caddr, rstride, c);
+                block_wait<0>(c);
+                T r;
+                if constexpr (NIND == 1) r = row_fma<T, O>(c, b[0]);
+                else r = slab_fma<T, O>(c, b[0], b[1]);
+                nt_store(&out[dep * ostride + n], r);
+                caddr += dstride;
+            }
+        } else {
+            const unsigned s0 = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
+            const unsigned s1 = (unsigned)d.cstride[2] * (unsigned)sizeof(T);
+            for (int dep = 0; dep < d.nDep; ++dep) {
+                T acc = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T c[O][O];
+                    block_issue<T, O, O>(caddr + (unsigned)a * s0, s1, c);
+                    block_wait<0>(c);
+                    acc += b[0][a] * slab_fma<T, O>(c, b[1], b[2]);
+                }
+                nt_store(&out[dep * ostride + n], acc);
+                caddr += dstride;
+            }
+        }
+    }
+}
+
+// fused jacobian of the same shapes.  out[(dep * NIND + j) * N + n]
+template <typename T, int NIND, int O>
+__global__ __launch_bounds__(STREAM_BLOCK) void jac_stream_uni(const Desc<T> d, const UniDescN<T> un, const void *__restrict__ gimg,
+                                                               const Params<T> prm, const long long N, T *__restrict__ out,
+                                                               unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned img_a = (unsigned)(size_t)smem;
+    const unsigned coef_a = img_a + un.coef_off;
+    stage_linear(smem, gimg, un.img_bytes);
+    __syncthreads();
+    const unsigned dstride = (unsigned)d.cstride[0] * (unsigned)sizeof(T);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    T lo_r[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) lo_r[iv] = un.lo[iv];
+    T unx[NIND];
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) { unx[iv] = lo_r[iv]; if (n < N) unx[iv] = prm.p[iv][n]; }
+#pragma unroll
+    for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(unx[iv]));
+
+    for (; n < N; n += stride) {
+        T u[NIND];
+        bool outside = false;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) {
+            u[iv] = unx[iv];
+            outside |= (u[iv] < lo_r[iv]) | (u[iv] > un.hi[iv]);
+            unx[iv] = lo_r[iv];
+        }
+        if (n + stride < N) {
+#pragma unroll
+            for (int iv = 0; iv < NIND; ++iv) unx[iv] = prm.p[iv][n + stride];
+        }
+        if (outside) record_bad(bad, n);
+
+        int m[NIND];
+        T z[NIND];
+        uni_spans<T, NIND, true>(img_a, un, u, m, z);
+        T b[NIND][O], db[NIND][O];
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) uni_basis_d1<T, O>(z[iv], un.inv_h[iv], b[iv], db[iv]);
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(unx[iv]));
+        unsigned caddr = coef_a;
+#pragma unroll
+        for (int iv = 0; iv < NIND; ++iv) caddr += (unsigned)(m[iv] * d.cstride[iv + 1]) * (unsigned)sizeof(T);
+
+        for (int dep = 0; dep < d.nDep; ++dep) {
+            T *o = out + (long long)dep * NIND * N + n;
+            if constexpr (NIND == 1) {
+                T c[1][O];
+                block_issue<T, 1, O>(caddr, 0u, c);
+                block_wait<0>(c);
+                nt_store(&o[0], row_fma<T, O>(c, db[0]));
+            } else if constexpr (NIND == 2) {
+                T c[O][O];
+                block_issue<T, O, O>(caddr, (unsigned)d.cstride[1] * (unsigned)sizeof(T), c);
+                block_wait<0>(c);
+                T j0 = T(0), j1 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T t = T(0), tdv = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) { t += c[a][k] * b[1][k]; tdv += c[a][k] * db[1][k]; }
+                    j0 += t * db[0][a];
+                    j1 += tdv * b[0][a];
+                }
+                nt_store(&o[0], j0);
+                nt_store(&o[N], j1);
+            } else {
+                const unsigned s0 = (unsigned)d.cstride[1] * (unsigned)sizeof(T);
+                const unsigned s1 = (unsigned)d.cstride[2] * (unsigned)sizeof(T);
+                T j0 = T(0), j1 = T(0), j2 = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) {
+                    T c[O][O];
+                    block_issue<T, O, O>(caddr + (unsigned)a * s0, s1, c);
+                    block_wait<0>(c);
+                    T sv = T(0), sb = T(0), sc = T(0);
+#pragma unroll
+                    for (int k = 0; k < O; ++k) {
+                        T t = T(0), tdv = T(0);
+#pragma unroll
+                        for (int mm = 0; mm < O; ++mm) { t += c[k][mm] * b[2][mm]; tdv += c[k][mm] * db[2][mm]; }
+                        sv += t * b[1][k];
+                        sb += t * db[1][k];
+                        sc += tdv * b[1][k];
+                    }
+                    j0 += sv * db[0][a];
+                    j1 += sb * b[0][a];
+                    j2 += sc * b[0][a];
+                }
+                nt_store(&o[0], j0);
+                nt_store(&o[N], j1);
+                nt_store(&o[2 * N], j2);
+            }
+            caddr += dstride;
+        }
+    }
+}
+
 }  // namespace bsk

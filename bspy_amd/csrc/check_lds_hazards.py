@@ -8,17 +8,17 @@ with the hardware's rule - LDS operations return in order, `lgkmcnt(N)` waits un
 outstanding - and fails the build when
 
   * any instruction reads or writes a VGPR that is the destination of an outstanding LDS read, or
-  * the paths into a basic block disagree about which reads are outstanding (the analysis is a
-    forward data-flow over the control-flow graph; the state of a block is that of the incoming
-    path that has waited least, and the other paths' states must be suffixes of it), or reads
-    pile up around a loop.
+  * reads pile up around a loop (the analysis is a forward data-flow over the control-flow graph;
+    the states of a block are those of its incoming paths, a path that has waited less standing
+    for the paths whose outstanding reads are a suffix of its own).
 
 usage: check_lds_hazards.py <device .s> [--allow-none] [kernel-name-substring ...]
 """
 import re
 import sys
 
-KERNELS = ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni")
+KERNELS = ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni",
+           "eval_cellsort")      # regular expressions on the mangled name
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 WAIT = re.compile(r"lgkmcnt\((\d+)\)")
 
@@ -132,19 +132,28 @@ def run_block(block, fifo, errors=None):
     return fifo
 
 
-def merge(a, b):
-    """in-state of a block reached with states a and b: the one that has waited less (the other
-    must be its suffix); None = not reached yet"""
-    if a is None:
-        return b
-    if b is None:
-        return a
-    long, short = (a, b) if len(a) >= len(b) else (b, a)
-    if not any(f[0] for f in a) and not any(f[0] for f in b):
-        return long                                # only stores / scalar loads pending: counts, no registers
-    if short and long[len(long) - len(short):] != short:
-        return "diverged"
-    return long
+def covers(long, short):
+    """every read outstanding in `short` is outstanding in `long` in the same place from the young end: whatever
+    holds after replaying `long` holds after `short`"""
+    if len(long) < len(short):
+        return False
+    if not any(f[0] for f in long) and not any(f[0] for f in short):
+        return True                                # only stores / scalar loads pending: counts, no registers
+    return not short or long[len(long) - len(short):] == short
+
+
+MAX_STATES = 32
+
+
+def merge(states, out):
+    """in-states of a block (a tuple of alternatives, None = not reached yet) joined with one more incoming state:
+    a state that another one covers is dropped.  Paths whose outstanding reads are unrelated (the compiler's own
+    reads in the branches of compiler-managed code) are kept side by side and each is replayed."""
+    if states is None:
+        return (out,)
+    if any(covers(st, out) for st in states):
+        return states
+    return tuple(st for st in states if not covers(out, st)) + (out,)
 
 
 def check_kernel(name, lines):
@@ -152,32 +161,37 @@ def check_kernel(name, lines):
     errors = []
     blocks = split_blocks(lines)
     state = [None] * len(blocks)
-    state[0] = ()
+    state[0] = ((),)
     work = [0]
     rounds = 0
-    while work:
+    while work and not errors:
         rounds += 1
         if rounds > 100000:
             errors.append((0, "data-flow did not converge", ""))
             break
         i = work.pop()
-        out = run_block(blocks[i], state[i])
-        if len(out) > 64:
-            errors.append((blocks[i]["insts"][0][0], "LDS operations pile up along a loop (never awaited)", ""))
-            break
-        for j in blocks[i]["succ"]:
-            m = merge(state[j], out)
-            if m == "diverged":
-                ln = blocks[j]["insts"][0][0] if blocks[j]["insts"] else 0
-                errors.append((ln, "paths into " + "/".join(blocks[j]["labels"]) + " differ in their outstanding LDS reads", ""))
-                continue
-            if m != state[j]:
-                state[j] = m
-                work.append(j)
+        for st in state[i]:
+            out = run_block(blocks[i], st)
+            if len(out) > 64:
+                errors.append((blocks[i]["insts"][0][0], "LDS operations pile up along a loop (never awaited)", ""))
+                break
+            for j in blocks[i]["succ"]:
+                m = merge(state[j], out)
+                if len(m) > MAX_STATES:
+                    ln = blocks[j]["insts"][0][0] if blocks[j]["insts"] else 0
+                    errors.append((ln, "too many unrelated sets of outstanding LDS reads reach " + "/".join(blocks[j]["labels"]), ""))
+                    break
+                if m != state[j]:
+                    state[j] = m
+                    if j not in work:
+                        work.append(j)
+            if errors:
+                break
     if not errors:
-        for b, st in zip(blocks, state):
-            if st is not None:
+        for b, sts in zip(blocks, state):
+            for st in sts or ():
                 run_block(b, st, errors)
+        errors = sorted(set(errors))
     return errors
 
 
@@ -192,7 +206,7 @@ def main():
         for ln, raw in enumerate(f, 1):
             if cur is None:
                 m = re.match(r"^(_Z\w+):", raw)
-                if m and any(k in m.group(1) for k in wanted):
+                if m and any(re.search(k, m.group(1)) for k in wanted):
                     cur = m.group(1)
                     kernels[cur] = []
                 continue
