@@ -691,7 +691,7 @@ __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, co
 }
 
 template <typename T, int O, int ND, bool MFMA>
-__global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
                                                      BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
@@ -709,9 +709,11 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
     T *bun = reinterpret_cast<T *>(smem + tab_b);
     BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + tab_b + bun_b);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(CS_TILE + 4 * S2));
-    unsigned *segs = hist + CS_MAX_S2;                      // segment start of every span, then [CS_MAX_S2] = padded total
+    unsigned *segs = hist + 2 * CS_MAX_S2;                  // segment start of every span
     __shared__ int s_first;
+    int tile_no = 0;
     for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
+    for (int i = threadIdx.x; i < 2 * CS_MAX_S2; i += blockDim.x) hist[i] = 0u;
     const long long per = (N + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
     if (threadIdx.x == 0) {
@@ -757,19 +759,22 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
             }
         }
         using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
-        // records of the first tile of this bin; every later tile is fetched while its predecessor is evaluated
-        BinRec<T, 3> rc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long p = sl + i * 256 + (long long)threadIdx.x;
-            rc[i] = rec[p < sh ? p : sh - 1];
-        }
         for (long long t0 = sl; t0 < sh; t0 += CS_TILE) {
             const int cnt = (int)((sh - t0) < CS_TILE ? (sh - t0) : CS_TILE);
-            __syncthreads();                                 // bundle staged / previous tile's readers are done
-            for (int k = threadIdx.x; k < S2; k += blockDim.x) hist[k] = 0u;
-            __syncthreads();
-            // --- span of the third variable, rank inside it
+            // Two barriers per tile.  The histograms alternate: this tile counts in `hc` (zeroed one tile ago), and
+            // clears `hn` for the next one after barrier (A).
+            unsigned *hc = hist + (tile_no & 1) * CS_MAX_S2, *hn = hist + ((tile_no & 1) ^ 1) * CS_MAX_S2;
+            ++tile_no;
+            // the tile's records (their lines were touched one tile ago: L2 hits; keeping them in registers across the
+            // evaluation of the previous tile costs 16 registers and, with them, the fourth wave per SIMD)
+            typedef T cs_rec4 __attribute__((ext_vector_type(4)));
+            cs_rec4 rc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long p = t0 + i * 256 + (long long)threadIdx.x;
+                rc[i] = *reinterpret_cast<const cs_rec4 *>(&rec[p < sh ? p : sh - 1]);
+            }
+            // --- rank inside the span of the third variable
             int key[4];
             unsigned rank[4];
 #pragma unroll
@@ -777,50 +782,47 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                 const int idx = i * 256 + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
-                    key[i] = (int)(unsigned)__builtin_bit_cast(Tag, rc[i].v[3]);      // found by the scatter kernel (rec_key)
-                    rank[i] = atomicAdd(&hist[key[i]], 1u);
+                    key[i] = (int)(unsigned)__builtin_bit_cast(Tag, (T)rc[i][3]);      // found by the scatter kernel (rec_key)
+                    rank[i] = atomicAdd(&hc[key[i]], 1u);
                 }
             }
-            __syncthreads();
-            // --- segment starts: exclusive scan of the counts rounded up to multiples of four (one wave)
-            if (wave == 0) {
-                unsigned carry = 0;
-                for (int k0 = 0; k0 < S2; k0 += 64) {
-                    const int k = k0 + lane;
-                    const unsigned v = k < S2 ? ((hist[k] + 3u) & ~3u) : 0u;
-                    unsigned inc = v;
+            __syncthreads();                                 // (A) counts complete; bundle staged; previous tile's readers of srec done
+            // --- segment starts: exclusive scan of the counts rounded up to multiples of four.  EVERY wave scans and
+            // writes the same values (a wave reads back its own LDS writes in order: no barrier before the look-ups)
+            unsigned carry = 0;
+            for (int k0 = 0; k0 < S2; k0 += 64) {
+                const int k = k0 + lane;
+                const unsigned v = k < S2 ? ((hc[k] + 3u) & ~3u) : 0u;
+                unsigned inc = v;
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const unsigned o = __shfl_up(inc, off);
-                        if (lane >= off) inc += o;
-                    }
-                    if (k < S2) segs[k] = carry + inc - v;
-                    carry += __shfl(inc, 63);
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_up(inc, off);
+                    if (lane >= off) inc += o;
                 }
-                if (lane == 0) segs[CS_MAX_S2] = carry;
+                if (k < S2) segs[k] = carry + inc - v;
+                carry += __shfl(inc, 63);
             }
-            __syncthreads();
+            const int total = (int)__builtin_amdgcn_readfirstlane((int)carry);
+            for (int k = threadIdx.x; k < S2; k += blockDim.x) hn[k] = 0u;
             // --- records into span order; the tag keeps the original position (tmp slot) and the span
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (key[i] >= 0) {
-                    BinRec<T, 3> r = rc[i];
+                    cs_rec4 r = rc[i];
                     const unsigned tag = (unsigned)(i * 256 + (int)threadIdx.x) | ((unsigned)key[i] << 16);
-                    r.v[3] = __builtin_bit_cast(T, (Tag)tag);
-                    srec[segs[key[i]] + rank[i]] = r;
+                    r[3] = __builtin_bit_cast(T, (Tag)tag);
+                    *reinterpret_cast<cs_rec4 *>(&srec[segs[key[i]] + rank[i]]) = r;
                 }
             }
-            // next tile's records travel during this tile's evaluation
+            // touch the lines of the next tile's records (one dword per 128-byte line), consumed after the evaluation
+            T touch = T(0);
             if (t0 + CS_TILE < sh) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long long p = t0 + CS_TILE + i * 256 + (long long)threadIdx.x;
-                    rc[i] = rec[p < sh ? p : sh - 1];
-                }
+                const long long p = t0 + CS_TILE + (long long)threadIdx.x * (128 / (long long)sizeof(BinRec<T, 3>));
+                if (threadIdx.x < CS_TILE * sizeof(BinRec<T, 3>) / 128 && p < sh) touch = rec[p].v[0];
             }
             // padding lanes of a segment: a point inside the same cell, tagged invalid (no store)
             for (int k = threadIdx.x; k < S2; k += blockDim.x) {
-                const unsigned have = hist[k], want = (have + 3u) & ~3u;
+                const unsigned have = hc[k], want = (have + 3u) & ~3u;
                 if (have != want) {
                     BinRec<T, 3> r;
                     r.v[0] = d.lo[0];
@@ -831,9 +833,8 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                     for (unsigned p = have; p < want; ++p) srec[segs[k] + p] = r;
                 }
             }
-            __syncthreads();
+            __syncthreads();                                 // (B) tile in span order
             // --- evaluation in span order
-            const int total = (int)segs[CS_MAX_S2];
             for (int g = wave * 64; g < total; g += 256) {
                 const int q = g + lane;
                 const bool live = q < total;
@@ -891,6 +892,7 @@ __global__ __launch_bounds__(256) void eval_cellsort(const Desc<T> d, const BinP
                     tmp[t0 + idx] = o;        // (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
                 }
             }
+            asm volatile("" :: "v"(touch));
         }
     }
 }

@@ -117,7 +117,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         size_t cs_lds_mfma = 0, cs_lds_valu = 0;
         if constexpr (NIND == 3 && !MIXED) {
             const int S2 = s->ncoef[2] - s->order[2] + 1;
-            const size_t rec_b = 4 * sizeof(T) * (size_t)(CS_TILE + 4 * S2) + sizeof(unsigned) * (size_t)(2 * CS_MAX_S2 + 4);
+            const size_t rec_b = 4 * sizeof(T) * (size_t)(CS_TILE + 4 * S2) + sizeof(unsigned) * (size_t)(3 * CS_MAX_S2 + 4);
             auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
             cs_lds_mfma = tab_b + up16(sizeof(T) * (size_t)O * O * 4 * s->ncoef[2]) + rec_b;
             cs_lds_valu = tab_b + up16(sizeof(T) * (size_t)O * O * s->nDep * s->ncoef[2]) + rec_b;
