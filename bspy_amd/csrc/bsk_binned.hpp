@@ -236,6 +236,7 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
 //                     result from LDS at Lb[bin] + (slot[n] - run start) and the SoA rows are stored coalesced
 // ---------------------------------------------------------------------------------------------
 constexpr int WC_PPT = 8;             // points per lane of a 1024-lane workgroup: chunk <= 8192
+constexpr int BIN_MAX_WC_CELLS = 2048; // bins the write-combining kernels hold tables for
 
 template <typename T, int NIND>
 __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const Params<T> prm, const long long N,
@@ -253,66 +254,86 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
     unsigned *next0 = locb + cells;
     BinRec<T, NIND> *srec = reinterpret_cast<BinRec<T, NIND> *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15));
     unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
-    const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
-    const int cnt = (int)(hi - lo);
-    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
-        lcnt[i] = 0u;
-        next0[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
-    }
-    __syncthreads();
-    unsigned ck[WC_PPT], rk[WC_PPT];
+    // PERSISTENT: one workgroup per CU (the chunk fills LDS) walks the chunks blockIdx, blockIdx + grid, ...  The next
+    // chunk's points, bins and run starts are fetched into registers BEFORE the store phase of the current one, so that
+    // loads and stores of a CU overlap (one chunk per workgroup: load, order, store one after the other, 125 us).
+    constexpr int NEXT_PPT = (BIN_MAX_WC_CELLS + 1023) / 1024;
+    unsigned ck[WC_PPT], rk[WC_PPT], nx[NEXT_PPT];
     BinRec<T, NIND> r[WC_PPT];
+    auto fetch = [&](int c) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
 #pragma unroll
-    for (int k = 0; k < WC_PPT; ++k) {
-        const int i = k * 1024 + (int)threadIdx.x;
-        const long long nn = lo + (i < cnt ? i : cnt - 1);
-        ck[k] = cell[nn];
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            const long long nn = lo + (i < cnt ? i : cnt - 1);
+            ck[k] = cell[nn];
 #pragma unroll
-        for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
+            for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
 #pragma unroll
-        for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
-    }
+            for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
+        }
 #pragma unroll
-    for (int k = 0; k < WC_PPT; ++k)
-        if (k * 1024 + (int)threadIdx.x < cnt) rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
-    if (keyed) {
+        for (int k = 0; k < NEXT_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            nx[k] = i < cells ? start[i] + M[(size_t)i * bp.chunks + c] : 0u;
+        }
+    };
+    int c = blockIdx.x;
+    if (c < bp.chunks) fetch(c);
+    for (; c < bp.chunks; c += gridDim.x) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+        __syncthreads();                                          // the previous chunk's store phase is done with LDS
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                                   // exclusive scan of the bin counts (one wave)
-        const int lane = threadIdx.x;
-        unsigned carry = 0;
-        for (int b0 = 0; b0 < cells; b0 += 64) {
-            const int b = b0 + lane;
-            const unsigned v = b < cells ? lcnt[b] : 0u;
-            unsigned inc = v;
+        for (int k = 0; k < NEXT_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cells) { lcnt[i] = 0u; next0[i] = nx[k]; }
+        }
+        __syncthreads();
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_up(inc, off);
-                if (lane >= off) inc += o;
+        for (int k = 0; k < WC_PPT; ++k)
+            if (k * 1024 + (int)threadIdx.x < cnt) rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
+        if (keyed) {
+#pragma unroll
+            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                                   // exclusive scan of the bin counts (one wave)
+            const int lane = threadIdx.x;
+            unsigned carry = 0;
+            for (int b0 = 0; b0 < cells; b0 += 64) {
+                const int b = b0 + lane;
+                const unsigned v = b < cells ? lcnt[b] : 0u;
+                unsigned inc = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned o = __shfl_up(inc, off);
+                    if (lane >= off) inc += o;
+                }
+                if (b < cells) locb[b] = carry + inc - v;
+                carry += __shfl(inc, 63);
             }
-            if (b < cells) locb[b] = carry + inc - v;
-            carry += __shfl(inc, 63);
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < WC_PPT; ++k) {
-        const int i = k * 1024 + (int)threadIdx.x;
-        if (i < cnt) {
-            const unsigned p = locb[ck[k]] + rk[k];
-            srec[p] = r[k];
-            sbin[p] = (unsigned short)ck[k];
-            slot[lo + i] = next0[ck[k]] + rk[k];
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cnt) {
+                const unsigned p = locb[ck[k]] + rk[k];
+                srec[p] = r[k];
+                sbin[p] = (unsigned short)ck[k];
+                slot[lo + i] = next0[ck[k]] + rk[k];
+            }
         }
-    }
-    for (int i = threadIdx.x; i < cells; i += blockDim.x) Lb[(size_t)blockIdx.x * cells + i] = locb[i];
-    __syncthreads();
-    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
-        const unsigned b = sbin[p];
-        rec[next0[b] + ((unsigned)p - locb[b])] = srec[p];
-        pbin[lo + p] = (unsigned short)b;
+        for (int i = threadIdx.x; i < cells; i += blockDim.x) Lb[(size_t)c * cells + i] = locb[i];
+        if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);     // in flight during the store phase
+        __syncthreads();
+        for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+            const unsigned b = sbin[p];
+            rec[next0[b] + ((unsigned)p - locb[b])] = srec[p];
+            pbin[lo + p] = (unsigned short)b;
+        }
     }
 }
 
@@ -655,24 +676,30 @@ __device__ __forceinline__ void cs_wait_row(CsRow<O> &row)
 }
 
 template <int O, int ND, int ROW>
-__device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O],
+__device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O], float wgt,
                                         CsRow<O> (&buf)[CS_AHEAD + 1], cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1],
                                         cs_f4 (&accr)[(O % 4) > 0 ? (O % 4) : 1])
 {
     constexpr int ROWS = O * O, G = O / 4, R = O % 4, NS = CS_AHEAD + 1;
     if constexpr (ROW < ROWS) {
         if constexpr (ROW + CS_AHEAD < ROWS) cs_issue_row<O, ROW + CS_AHEAD>(a_addr, r_addr, buf[(ROW + CS_AHEAD) % NS]);
+        // the next row's weight is formed a row early (pinned above this row's wait): a product right in front of the
+        // MFMA that reads it costs wait states
+        float wnext = 0.f;
+        if constexpr (ROW + 1 < ROWS) {
+            wnext = b0[(ROW + 1) / O] * b1[(ROW + 1) % O];
+            asm volatile("" : "+v"(wnext) :: "memory");
+        }
         constexpr int later = ROWS - 1 - ROW < CS_AHEAD ? ROWS - 1 - ROW : CS_AHEAD;
         CsRow<O> &row = buf[ROW % NS];
         cs_wait_row<O, (G + R) * later>(row);
-        const float wgt = b0[ROW / O] * b1[ROW % O];
         if constexpr (G >= 1) {
 #pragma unroll
             for (int dd = 0; dd < ND; ++dd) accg[dd] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.g[0][dd], wgt, accg[dd], 0, 0, 0);
         }
 #pragma unroll
         for (int r2 = 0; r2 < R; ++r2) accr[r2] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.r[r2], wgt, accr[r2], 0, 0, 0);
-        cs_rows<O, ND, ROW + 1>(a_addr, r_addr, b0, b1, buf, accg, accr);
+        cs_rows<O, ND, ROW + 1>(a_addr, r_addr, b0, b1, wnext, buf, accg, accr);
     }
 }
 
@@ -687,7 +714,7 @@ __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, co
     if constexpr (ROWS > 2 && CS_AHEAD > 2) cs_issue_row<O, 2>(a_addr, r_addr, buf[2]);
     if constexpr (ROWS > 3 && CS_AHEAD > 3) cs_issue_row<O, 3>(a_addr, r_addr, buf[3]);
     static_assert(CS_AHEAD <= 4, "prologue");
-    cs_rows<O, ND, 0>(a_addr, r_addr, b0, b1, buf, accg, accr);
+    cs_rows<O, ND, 0>(a_addr, r_addr, b0, b1, b0[0] * b1[0], buf, accg, accr);
 }
 
 template <typename T, int O, int ND, bool MFMA>
@@ -712,6 +739,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
     unsigned *segs = hist + 2 * CS_MAX_S2;                  // segment start of every span
     __shared__ int s_first;
     int tile_no = 0;
+    // Records per tile: with the padding of its S2 segments (0 .. 3 lanes each, 1.5 on average) a tile should fill the
+    // 16 wave passes of the four waves and not start a 17th that one wave runs while three wait: 1024 - 2 S2 - 8.
+    const int tile = CS_TILE - 2 * S2 - 8 >= CS_TILE / 2 ? CS_TILE - 2 * S2 - 8 : CS_TILE / 2;
     for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
     for (int i = threadIdx.x; i < 2 * CS_MAX_S2; i += blockDim.x) hist[i] = 0u;
     const long long per = (N + gridDim.x - 1) / gridDim.x;
@@ -759,8 +789,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             }
         }
         using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
-        for (long long t0 = sl; t0 < sh; t0 += CS_TILE) {
-            const int cnt = (int)((sh - t0) < CS_TILE ? (sh - t0) : CS_TILE);
+        for (long long t0 = sl; t0 < sh; t0 += tile) {
+            const int cnt = (int)((sh - t0) < tile ? (sh - t0) : tile);
             // Two barriers per tile.  The histograms alternate: this tile counts in `hc` (zeroed one tile ago), and
             // clears `hn` for the next one after barrier (A).
             unsigned *hc = hist + (tile_no & 1) * CS_MAX_S2, *hn = hist + ((tile_no & 1) ^ 1) * CS_MAX_S2;
@@ -816,8 +846,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             }
             // touch the lines of the next tile's records (one dword per 128-byte line), consumed after the evaluation
             T touch = T(0);
-            if (t0 + CS_TILE < sh) {
-                const long long p = t0 + CS_TILE + (long long)threadIdx.x * (128 / (long long)sizeof(BinRec<T, 3>));
+            if (t0 + tile < sh) {
+                const long long p = t0 + tile + (long long)threadIdx.x * (128 / (long long)sizeof(BinRec<T, 3>));
                 if (threadIdx.x < CS_TILE * sizeof(BinRec<T, 3>) / 128 && p < sh) touch = rec[p].v[0];
             }
             // padding lanes of a segment: a point inside the same cell, tagged invalid (no store)

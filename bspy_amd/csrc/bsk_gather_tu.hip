@@ -73,7 +73,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         // beside three (two) bin tables; BSK_VARIANT 14 keeps the direct forms
         const size_t rec_sz = sizeof(BinRec<T, NIND>), out_sz_max = (4 * sizeof(T) + 15) / 16 * 16;
         long long wc_chunk = 0;
-        if (bp.cells <= 2048 && s->variant != 14 && s->variant != 13) {
+        if (bp.cells <= BIN_MAX_WC_CELLS && s->variant != 14 && s->variant != 13) {
             const size_t room = s->lds_max - 12 * (size_t)bp.cells - 256;
             wc_chunk = (long long)(room / (std::max(rec_sz, out_sz_max) + 2)) / 1024 * 1024;
             wc_chunk = std::min<long long>(wc_chunk, 1024 * WC_PPT);
@@ -147,7 +147,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         if (wc) {                                                                                                        \
             const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
-            hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(bp.chunks), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
+            hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
                                start, rec, slot, pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \

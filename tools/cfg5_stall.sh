@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: bash tools/cfg5_stall.sh <tag> [BSK_VARIANT] - wave-level issue / wait counters of the cfg5 kernels (two PMC passes)
-tag=$1; export TMPDIR=/tmp
+tag=$1; export TMPDIR=/tmp; export CFG5_ITERS=${CFG5_ITERS:-3,5}
 [ -n "$2" ] && export BSK_VARIANT=$2
 out=$PWD/gpurun_out/stall_cfg5_$tag
 rm -rf $out; mkdir -p $out
