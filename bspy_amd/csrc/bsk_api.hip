@@ -170,6 +170,8 @@ static bsk_status init_desc(bsk_spline s)
 
 template <typename T>
 static bsk_status upload_uniform(bsk_spline s, const void *const *knots, const void *coefs);   // uniform-knot surface path
+template <typename T>
+static bsk_status upload_uniform_nd(bsk_spline s, const void *const *knots, const void *coefs);   // ... of the other LDS-resident shapes
 
 extern "C" int bsk_version(void) { return BSK_VERSION; }
 extern "C" const char *bsk_last_error(void) { return g_err.c_str(); }
@@ -263,6 +265,7 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
 #undef HIPCHK_C
     st = dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
     if (st == BSK_OK) st = dtype == BSK_F32 ? upload_uniform<float>(s, knots, coefs) : upload_uniform<double>(s, knots, coefs);
+    if (st == BSK_OK) st = dtype == BSK_F32 ? upload_uniform_nd<float>(s, knots, coefs) : upload_uniform_nd<double>(s, knots, coefs);
     if (st != BSK_OK) { s->uni_img.release(); cleanup(); return st; }
     *out = s;
     return BSK_OK;
@@ -275,7 +278,9 @@ extern "C" bsk_status bsk_spline_update(bsk_spline s, const void *const *knots, 
     HIPCHK(hipDeviceSynchronize());
     const bsk_status st = s->dtype == BSK_F32 ? upload_tables<float>(s, knots, coefs) : upload_tables<double>(s, knots, coefs);
     if (st != BSK_OK) return st;
-    return s->dtype == BSK_F32 ? upload_uniform<float>(s, knots, coefs) : upload_uniform<double>(s, knots, coefs);
+    const bsk_status su = s->dtype == BSK_F32 ? upload_uniform<float>(s, knots, coefs) : upload_uniform<double>(s, knots, coefs);
+    if (su != BSK_OK) return su;
+    return s->dtype == BSK_F32 ? upload_uniform_nd<float>(s, knots, coefs) : upload_uniform_nd<double>(s, knots, coefs);
 }
 
 extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
@@ -647,6 +652,78 @@ static bsk_status upload_uniform(bsk_spline s, const void *const *knots, const v
     return BSK_OK;
 }
 
+// The same image for curves, surfaces of order 1 / 3 / 5 and volumes (eval_stream_uni / jac_stream_uni):
+// [domain knots of every variable][coefficients, unclamped, in the reference's (nDep, nCoef...) layout].
+// Unclamping a variable multiplies the rounding errors of its boundary control points by the largest absolute row
+// sum of its matrix; the path is taken while the product over the variables stays below 5000 (three variables of
+// order 5 exceed it) and, as for surfaces, in fp64 only unless nothing has to be unclamped (order <= 2).
+static size_t tile_lds_bytes_any(bsk_spline s);
+template <typename T>
+static bsk_status upload_uniform_nd(bsk_spline s, const void *const *knots, const void *coefs)
+{
+    s->uniN = false;
+    if (s->uni || !has_fixed_path(s) || s->variant != 0 || s->order[0] > 5 || tile_lds_bytes_any(s) == 0) return BSK_OK;
+    const int O = s->order[0], nInd = s->nInd, nDep = s->nDep;
+    bool cl[3][2];
+    for (int iv = 0; iv < nInd; ++iv) {
+        if (s->ncoef[iv] < 2 * O) return BSK_OK;                       // the two ends must not overlap
+        if (!axis_is_uniform<T>(static_cast<const T *>(knots[iv]), O, s->ncoef[iv], cl[iv][0], cl[iv][1])) return BSK_OK;
+    }
+    if (sizeof(T) == 4 && O > 2) return BSK_OK;
+    std::vector<long double> M;
+    if (!unclamp_matrix(O, M)) return BSK_OK;
+    long double growth = 0, total = 1;
+    for (int i = 0; i < O; ++i) {
+        long double rsum = 0;
+        for (int j = 0; j < O; ++j) rsum += std::fabs(M[(size_t)i * O + j]);
+        growth = std::max(growth, rsum);
+    }
+    for (int iv = 0; iv < nInd; ++iv) if (cl[iv][0] || cl[iv][1]) total *= growth;
+    if (total > 5000.0L) return BSK_OK;
+    size_t ncp = 1;
+    for (int iv = 0; iv < nInd; ++iv) ncp *= (size_t)s->ncoef[iv];
+    std::vector<long double> w((size_t)nDep * ncp);
+    const T *src = static_cast<const T *>(coefs);
+    for (size_t i = 0; i < w.size(); ++i) w[i] = src[i];
+    size_t outer = (size_t)nDep, inner = ncp;
+    for (int iv = 0; iv < nInd; ++iv) {
+        inner /= (size_t)s->ncoef[iv];
+        if (cl[iv][0]) unclamp_axis(w, outer, s->ncoef[iv], inner, O, M, true);
+        if (cl[iv][1]) unclamp_axis(w, outer, s->ncoef[iv], inner, O, M, false);
+        outer *= (size_t)s->ncoef[iv];
+    }
+    UniDescN<T> &un = uniN_of<T>(s);
+    memset(&un, 0, sizeof(un));
+    unsigned off = 0;
+    int nsmax = 1;
+    for (int iv = 0; iv < nInd; ++iv) {
+        const T *k = static_cast<const T *>(knots[iv]);
+        un.ns[iv] = s->ncoef[iv] - O + 1;
+        un.lo[iv] = k[O - 1];
+        un.hi[iv] = k[s->ncoef[iv]];
+        un.inv_h[iv] = T((long double)un.ns[iv] / ((long double)un.hi[iv] - (long double)un.lo[iv]));
+        un.kn_off[iv] = off;
+        off += (unsigned)((un.ns[iv] + 1) * sizeof(T));
+        nsmax = std::max(nsmax, un.ns[iv]);
+    }
+    un.eps = T(std::max<long double>(sizeof(T) == 8 ? 0x1p-30L : 0x1p-12L, 16.0L * nsmax * std::numeric_limits<T>::epsilon()));
+    off = (off + 15u) & ~15u;
+    un.coef_off = off;
+    const size_t total_b = (size_t)off + (((size_t)nDep * ncp * sizeof(T) + 15) & ~(size_t)15);
+    if (total_b > s->lds_max) return BSK_OK;
+    un.img_bytes = (unsigned)total_b;
+    std::vector<unsigned char> img(total_b, 0);
+    for (int iv = 0; iv < nInd; ++iv)
+        memcpy(img.data() + un.kn_off[iv], static_cast<const T *>(knots[iv]) + O - 1, (size_t)(un.ns[iv] + 1) * sizeof(T));
+    T *ic = reinterpret_cast<T *>(img.data() + un.coef_off);
+    for (size_t i = 0; i < w.size(); ++i) ic[i] = T(w[i]);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(s->uni_img.reserve(total_b));
+    HIPCHK(hipMemcpy(s->uni_img.p, img.data(), total_b, hipMemcpyHostToDevice));
+    s->uniN = true;
+    return BSK_OK;
+}
+
 template <typename T, bool NORMAL>
 static bsk_status launch_jac_rowrot(bsk_spline s, const Params<T> &prm, long long n, T *out, int normalize, int negate,
                                     hipStream_t st)
@@ -795,6 +872,27 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
             return BSK_OK;
         }
     }
+    if constexpr (O <= 5) {
+        if (s->uniN) {
+            // equally spaced knots: table-free front end on the unclamped image (bsk_uniform.hpp)
+            const UniDescN<T> &un = uniN_of<T>(s);
+            const size_t lds_u = un.img_bytes;
+            const int per_cu_u = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_u));
+            const int grid_u = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu_u));
+            s->last_kernel = "eval_stream_uni";
+            if (deriv) {
+                HIPCHK(allow_lds(eval_stream_uni<T, NIND, O, true>, lds_u));
+                hipLaunchKernelGGL((eval_stream_uni<T, NIND, O, true>), dim3(grid_u), dim3(STREAM_BLOCK), lds_u, st, d, un, s->uni_img.p,
+                                   prm, n, out, ostride, w, s->bad);
+            } else {
+                HIPCHK(allow_lds(eval_stream_uni<T, NIND, O, false>, lds_u));
+                hipLaunchKernelGGL((eval_stream_uni<T, NIND, O, false>), dim3(grid_u), dim3(STREAM_BLOCK), lds_u, st, d, un, s->uni_img.p,
+                                   prm, n, out, ostride, w, s->bad);
+            }
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     if (deriv) {
@@ -816,6 +914,11 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
 static bool has_fixed_path(bsk_spline s)
 {
     return s->same_order && s->nInd >= 1 && s->nInd <= 3 && s->order[0] >= 1 && s->order[0] <= 6;
+}
+
+static size_t tile_lds_bytes_any(bsk_spline s)
+{
+    return s->dtype == BSK_F32 ? tile_lds_bytes<float>(s, false) : tile_lds_bytes<double>(s, false);
 }
 
 // The LDS-staging kernels (eval_fixed / jac_fixed / eval_mixed) keep at least the axis tables in LDS.
@@ -842,6 +945,20 @@ static bsk_status launch_jac_stream(bsk_spline s, size_t lds, const Params<T> &p
     const Desc<T> &d = desc_of<T>(s);
     const TileDesc<T> &td = tile_of<T>(s);
     const long long ntiles = (n + STREAM_BLOCK - 1) / STREAM_BLOCK;
+    if constexpr (O <= 5) {
+        if (s->uniN) {
+            const UniDescN<T> &un = uniN_of<T>(s);
+            const size_t lds_u = un.img_bytes;
+            const int per_cu_u = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_u));
+            const int grid_u = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu_u));
+            HIPCHK(allow_lds(jac_stream_uni<T, NIND, O>, lds_u));
+            s->last_kernel = "jac_stream_uni";
+            hipLaunchKernelGGL((jac_stream_uni<T, NIND, O>), dim3(grid_u), dim3(STREAM_BLOCK), lds_u, st, d, un, s->uni_img.p, prm, n,
+                               out, s->bad);
+            HIPCHK(hipGetLastError());
+            return BSK_OK;
+        }
+    }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds));
     const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)s->num_cu * per_cu));
     HIPCHK(allow_lds(jac_stream<T, NIND, O>, lds));

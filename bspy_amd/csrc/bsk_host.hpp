@@ -90,6 +90,10 @@ struct bsk_spline_s {
     UniDesc<float> u32;
     UniDesc<double> u64;
     DevBuf uni_img;
+    // the same front end for curves, surfaces of other orders and volumes (eval_stream_uni / jac_stream_uni): shares uni_img
+    bool uniN = false;
+    UniDescN<float> un32;
+    UniDescN<double> un64;
     const char *last_kernel = "";       // family of the most recent point-kernel launch (bsk_last_kernel)
 };
 
@@ -105,6 +109,12 @@ template <>
 inline UniDesc<float> &uni_of<float>(bsk_spline s) { return s->u32; }
 template <>
 inline UniDesc<double> &uni_of<double>(bsk_spline s) { return s->u64; }
+template <typename T>
+UniDescN<T> &uniN_of(bsk_spline s);
+template <>
+inline UniDescN<float> &uniN_of<float>(bsk_spline s) { return s->un32; }
+template <>
+inline UniDescN<double> &uniN_of<double>(bsk_spline s) { return s->un64; }
 template <typename T>
 TileDesc<T> &tile_of(bsk_spline s);
 template <>

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream_uni(const Desc<T> d,
 
         int m[NIND];
         T z[NIND];
-        uni_spans<T, NIND, DERIV>(img_a, un, u, m, z);
+        uni_spans<T, NIND, DERIV || O == 1>(img_a, un, u, m, z);   // order 1: the basis is 1 whatever u is, so the span of a NaN shows
         T b[NIND][O];
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) uni_basis<T, O, DERIV>(z[iv], DERIV ? wrt.w[iv] : 0, un.inv_h[iv], b[iv]);

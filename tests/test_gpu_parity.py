@@ -1337,3 +1337,85 @@ def test_uniform_path_declines_knots_far_from_the_origin():
     near = DeviceSpline((order, order), ncoef, [_uniform_knots(order, nc, 10.0, 10.5) for nc in ncoef], coefs)
     near.evaluate([rng.uniform(10.0, 10.5, 100), rng.uniform(10.0, 10.5, 100)])
     assert near.last_kernel() == "eval_uni"
+
+
+@pytest.mark.parametrize("order,ncoef,dom,clamps,nDep,dt,expect", [
+    (4, (40,), ((0.0, 1.0),), (True, True), 3, np.float64, True),                                  # cubic curve
+    (5, (33,), ((-1.0, 2.0),), (True, True), 1, np.float64, True),
+    (3, (12,), ((0.0, 1.0),), (False, True), 2, np.float64, True),                                 # continued, not clamped, at one end
+    (1, (7,), ((0.0, 1.0),), (True, True), 2, np.float64, True),                                   # piecewise constant
+    (2, (19,), ((0.0, 3.0),), (True, True), 2, np.float32, True),                                  # fp32: order <= 2 only
+    (4, (25,), ((0.0, 1.0),), (True, True), 2, np.float32, False),
+    (3, (20, 20), ((0.0, 1.0), (0.0, 2.0)), (True,) * 4, 3, np.float64, True),                      # surfaces of order 3 / 5
+    (5, (30, 30), ((0.0, 1.0), (0.0, 1.0)), (True,) * 4, 3, np.float64, True),
+    (5, (11, 14), ((2.0, 3.0), (-1.0, 0.0)), (True, False, True, True), 1, np.float64, True),
+    (4, (8, 9, 10), ((0.0, 1.0),) * 3, (True,) * 6, 1, np.float64, True),                           # volumes
+    (3, (12, 12, 12), ((0.0, 1.0), (0.0, 2.0), (1.0, 2.0)), (True,) * 6, 3, np.float64, True),
+    (2, (6, 7, 8), ((0.0, 1.0),) * 3, (True,) * 6, 2, np.float64, True),
+    (5, (10, 10, 10), ((0.0, 1.0),) * 3, (True,) * 6, 1, np.float64, False),                        # three clamped variables of order 5: declined
+])
+def test_uniform_knot_path_other_shapes(order, ncoef, dom, clamps, nDep, dt, expect):
+    """Curves, surfaces of order 1 / 3 / 5 and volumes with equally spaced knots: eval_stream_uni / jac_stream_uni
+    (table-free front end on the unclamped image) against the oracle - every derivative multi-index up to order + 1
+    in total, the fused jacobian, points on every knot and one ulp either side, NaN, out-of-domain index, update."""
+    rng = np.random.default_rng(123)
+    nInd = len(ncoef)
+    tol = 1e-12 if dt == np.float64 else 2e-5
+    knots = [_uniform_knots(order, nc, lo, hi, clamps[2 * i], clamps[2 * i + 1]).astype(dt) for i, (nc, (lo, hi)) in enumerate(zip(ncoef, dom))]
+    coefs = rng.standard_normal((nDep, *ncoef)).astype(dt)
+    orders = (order,) * nInd
+    t = DeviceSpline(orders, ncoef, knots, coefs, dt)
+    n = 12000
+    dm = [(float(k[order - 1]), float(k[nc])) for k, nc in zip(knots, ncoef)]
+    pts = [(lo + (hi - lo) * rng.random(n)).astype(dt).clip(dt(lo), dt(hi)) for lo, hi in dm]
+    at = 0
+    for i, (k, nc) in enumerate(zip(knots, ncoef)):
+        kk = np.unique(k[order - 1:nc + 1])
+        edge = np.concatenate([kk, np.nextafter(kk[1:], dt(-np.inf)), np.nextafter(kk[:-1], dt(np.inf))]).astype(dt)
+        pts[i][at:at + edge.size] = edge
+        at += edge.size
+    for i in range(nInd):
+        pts[i][-1], pts[i][-2] = dm[i][1], dm[i][0]
+    import itertools
+    wrts = [w for w in itertools.product(range(order + 1), repeat=nInd) if sum(w) <= order + 1]
+    ek, jk = ("eval_stream_uni", "jac_stream_uni") if expect else ("eval_stream", "jac_stream")
+    for w in wrts:
+        out = t.evaluate(pts, list(w))
+        assert t.last_kernel() == ek, (t.last_kernel(), w)
+        orc, bad = oracle.c_evaluate(orders, ncoef, knots, coefs, list(w), pts)
+        assert bad == -1
+        assert np.abs(out - orc).max() <= tol * _scale(orc), (w, np.abs(out - orc).max(), _scale(orc))
+    jac = t.jacobian(pts)
+    assert t.last_kernel() == jk or (not expect and t.last_kernel() == "jac_fixed")      # volumes of order 5
+    orj, _ = oracle.c_jacobian(orders, ncoef, knots, coefs, pts)
+    assert np.abs(jac - orj).max() <= tol * _scale(orj)
+    if not expect:
+        return
+    # NaN parameters propagate (derivative levels do not multiply by u: the span rule decides), out-of-domain by index
+    bad_pts = [p.copy() for p in pts]
+    bad_pts[0][123] = np.nan
+    if order > 1:
+        assert np.isnan(t.evaluate(bad_pts)[:, 123]).all()
+    else:       # piecewise constant: NaN sorts to the end, the last coefficient comes back (reference and oracle)
+        o1, _ = oracle.c_evaluate(orders, ncoef, knots, coefs, [0] * nInd, [p[123:124] for p in bad_pts])
+        assert np.array_equal(t.evaluate(bad_pts)[:, 123], o1[:, 0])
+    if order > 1:
+        w = [order - 1] + [0] * (nInd - 1)
+        d3 = t.evaluate(bad_pts, w)[:, 123]
+        o3, _ = oracle.c_evaluate(orders, ncoef, knots, coefs, w, [p[123:124] for p in bad_pts])
+        assert np.allclose(d3, o3[:, 0], rtol=100 * tol, atol=100 * tol * _scale(o3), equal_nan=True)
+    bad_pts[0][123] = dt(0.5 * (dm[0][0] + dm[0][1]))
+    bad_pts[-1][4567] = np.nextafter(dt(dm[-1][1]), dt(np.inf))
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad_pts)
+    assert e.value.index == 4567
+    coefs2 = coefs.copy()
+    coefs2[:, 0] += 1.0
+    t.update(knots, coefs2)
+    out2 = t.evaluate(pts)
+    assert t.last_kernel() == ek
+    orc2, _ = oracle.c_evaluate(orders, ncoef, knots, coefs2, [0] * nInd, pts)
+    assert np.abs(out2 - orc2).max() <= tol * _scale(orc2)
+
+
+
