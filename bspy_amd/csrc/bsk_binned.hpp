@@ -10,8 +10,9 @@
 //
 //   bin_count    one workgroup per contiguous chunk of the batch: spans of variables 0 and 1,
 //                domain test, LDS histogram over the cells; writes cell[n] and the chunk's
-//                histogram column M[cell][chunk]
-//   bin_rowscan  one workgroup per cell: exclusive scan over the chunks, cell total
+//                histogram row M[chunk][cell]
+//   bin_scan_ranges / bin_scan_totals  exclusive scan of every cell's counts over the chunks (ranges of chunks,
+//                then the ranges), cell totals
 //   bin_topscan  one workgroup: exclusive scan of the cell totals
 //   bin_scatter  same chunks: slot = start[cell] + M[cell][chunk] + rank inside the chunk (LDS
 //                atomic); writes the record {u..} to rec[slot] and slot[n]
@@ -40,7 +41,17 @@ struct BinPlan {
     int cells;          // total
     int chunks;         // workgroups of bin_count / bin_scatter
     long long chunk;    // points per chunk
+    int rlen, ranges;   // the chunks are scanned in `ranges` ranges of `rlen` chunks (bin_scan_ranges)
 };
+
+// First slot of the run of bin i in chunk c: the bin's start + the runs of the bin in earlier ranges + in earlier
+// chunks of the range.  M is kept [chunk][bin]: a chunk's histogram row is written, scanned and read coalesced
+// (as [bin][chunk] every workgroup of bin_count / bin_scatter / bin_unpermute touched `bins` different lines).
+__device__ __forceinline__ unsigned bin_run_start(const BinPlan &bp, const unsigned *__restrict__ start, const unsigned *__restrict__ Tr,
+                                                  const unsigned *__restrict__ M, int c, int i)
+{
+    return start[i] + Tr[(size_t)(c / bp.rlen) * bp.cells + i] + M[(size_t)c * bp.cells + i];
+}
 
 // record of one point in slot order: its parameters, padded to 16-byte multiples (one vector access)
 template <typename T, int NIND>
@@ -125,32 +136,38 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) M[(size_t)i * bp.chunks + blockIdx.x] = hist[i];
+    for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) M[(size_t)blockIdx.x * bp.cells + i] = hist[i];
 }
 
-// one workgroup per cell: M[cell][0..chunks) -> exclusive prefix, total[cell]; blocks of BIN_MAX_CHUNKS with a carry
-__global__ __launch_bounds__(BIN_MAX_CHUNKS) void bin_rowscan(const int chunks, unsigned *__restrict__ M,
-                                                              unsigned *__restrict__ total)
+// Scan of the chunk histograms along the chunks, in two steps.
+//   bin_scan_ranges  thread = bin, workgroup = 256 bins x one range of chunks: exclusive prefix inside the range
+//                    (in place), range total -> Tr[range][bin]; rows are read and written coalesced, eight in flight
+//   bin_scan_totals  thread = bin: exclusive prefix over the ranges (in place), bin total -> total[bin]
+__global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigned *__restrict__ M, unsigned *__restrict__ Tr)
 {
-    __shared__ unsigned s[BIN_MAX_CHUNKS];
-    unsigned *row = M + (size_t)blockIdx.x * chunks;
-    const int t = threadIdx.x;
-    unsigned carry = 0;
-    for (int c0 = 0; c0 < chunks; c0 += BIN_MAX_CHUNKS) {
-        const unsigned v = c0 + t < chunks ? row[c0 + t] : 0u;
-        __syncthreads();
-        s[t] = v;
-        __syncthreads();
-        for (int off = 1; off < BIN_MAX_CHUNKS; off <<= 1) {
-            const unsigned add = t >= off ? s[t - off] : 0u;
-            __syncthreads();
-            s[t] += add;
-            __syncthreads();
-        }
-        if (c0 + t < chunks) row[c0 + t] = carry + s[t] - v;
-        carry += s[BIN_MAX_CHUNKS - 1];
+    const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (i >= bp.cells) return;
+    const int c0 = r * bp.rlen, c1 = c0 + bp.rlen < bp.chunks ? c0 + bp.rlen : bp.chunks;
+    unsigned run = 0;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = M[(size_t)(c + k) * bp.cells + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { M[(size_t)(c + k) * bp.cells + i] = run; run += v[k]; }
     }
-    if (t == 0) total[blockIdx.x] = carry;
+    for (; c < c1; ++c) { const unsigned v = M[(size_t)c * bp.cells + i]; M[(size_t)c * bp.cells + i] = run; run += v; }
+    Tr[(size_t)r * bp.cells + i] = run;
+}
+
+__global__ __launch_bounds__(256) void bin_scan_totals(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= bp.cells) return;
+    unsigned run = 0;
+    for (int r = 0; r < bp.ranges; ++r) { const unsigned v = Tr[(size_t)r * bp.cells + i]; Tr[(size_t)r * bp.cells + i] = run; run += v; }
+    total[i] = run;
 }
 
 // one workgroup: total[0..cells) -> exclusive prefix in start[]
@@ -180,14 +197,15 @@ __global__ __launch_bounds__(1024) void bin_topscan(const int cells, const unsig
 template <typename T, int NIND>
 __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Params<T> prm, const long long N,
                                                          const unsigned short *__restrict__ cell,
-                                                         const unsigned *__restrict__ M, const unsigned *__restrict__ start,
+                                                         const unsigned *__restrict__ M, const unsigned *__restrict__ Tr,
+                                                         const unsigned *__restrict__ start,
                                                          BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
                                                          const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
                                                          const unsigned *__restrict__ glut, const int keyed)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *next = reinterpret_cast<unsigned *>(smem);
-    for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) next[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
+    for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) next[i] = bin_run_start(bp, start, Tr, M, blockIdx.x, i);
     __syncthreads();
     const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
     for (long long n0 = lo + threadIdx.x; n0 < hi; n0 += (long long)blockDim.x * BIN_ILP) {
@@ -241,7 +259,8 @@ constexpr int BIN_MAX_WC_CELLS = 2048; // bins the write-combining kernels hold 
 template <typename T, int NIND>
 __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const Params<T> prm, const long long N,
                                                        const unsigned short *__restrict__ cell,
-                                                       const unsigned *__restrict__ M, const unsigned *__restrict__ start,
+                                                       const unsigned *__restrict__ M, const unsigned *__restrict__ Tr,
+                                                       const unsigned *__restrict__ start,
                                                        BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
                                                        unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb,
                                                        const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
 #pragma unroll
         for (int k = 0; k < NEXT_PPT; ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
-            nx[k] = i < cells ? start[i] + M[(size_t)i * bp.chunks + c] : 0u;
+            nx[k] = i < cells ? bin_run_start(bp, start, Tr, M, c, i) : 0u;
         }
     };
     int c = blockIdx.x;
@@ -341,6 +360,7 @@ template <typename T, int ND>
 __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const long long N,
                                                          const unsigned short *__restrict__ cell,
                                                          const unsigned *__restrict__ slot, const unsigned *__restrict__ M,
+                                                         const unsigned *__restrict__ Tr,
                                                          const unsigned *__restrict__ start, const unsigned *__restrict__ Lb,
                                                          const unsigned short *__restrict__ pbin,
                                                          const BinOut<T, ND> *__restrict__ tmp, T *__restrict__ out,
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
     const int cnt = (int)(hi - lo);
     for (int i = threadIdx.x; i < cells; i += blockDim.x) {
         locb[i] = Lb[(size_t)blockIdx.x * cells + i];
-        next0[i] = start[i] + M[(size_t)i * bp.chunks + blockIdx.x];
+        next0[i] = bin_run_start(bp, start, Tr, M, blockIdx.x, i);
     }
     __syncthreads();
     for (int p = threadIdx.x; p < cnt; p += blockDim.x) {

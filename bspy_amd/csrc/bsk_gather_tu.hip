@@ -87,6 +87,9 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const int ugrid = env_unp > 0 ? env_unp : 2048;
 
         bp.chunk = (n + bp.chunks - 1) / bp.chunks;
+        bp.ranges = std::min(bp.chunks, 16);
+        bp.rlen = (bp.chunks + bp.ranges - 1) / bp.ranges;
+        bp.ranges = (bp.chunks + bp.rlen - 1) / bp.rlen;
         const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
         const TileDesc<T> &td = tile_of<T>(s);
         const size_t lds_count = tab_b + sizeof(unsigned) * (size_t)(bp.cells + ((td.lut_len + 3) & ~3));
@@ -95,11 +98,12 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t o_cell = 0, o_slot = o_cell + up(2 * (size_t)n), o_rec = o_slot + up(4 * (size_t)n);
         const size_t o_tmp = o_rec + up(sizeof(BinRec<T, NIND>) * (size_t)n);
-        size_t o_M = 0, o_tot = 0, o_start = 0, o_pbin = 0, o_Lb = 0, total = 0;
+        size_t o_M = 0, o_tot = 0, o_Tr = 0, o_start = 0, o_pbin = 0, o_Lb = 0, total = 0;
         auto layout = [&](size_t out_bytes) {
             o_M = o_tmp + up(out_bytes * (size_t)n);
             o_tot = o_M + up(4 * (size_t)bp.cells * bp.chunks);
-            o_start = o_tot + up(4 * (size_t)bp.cells);
+            o_Tr = o_tot + up(4 * (size_t)bp.cells);
+            o_start = o_Tr + up(4 * (size_t)bp.cells * bp.ranges);
             o_pbin = o_start + up(4 * (size_t)bp.cells);
             o_Lb = o_pbin + (wc ? up(2 * (size_t)n) : 0);
             total = o_Lb + (wc ? up(4 * (size_t)bp.cells * bp.chunks) : 0);
@@ -135,12 +139,14 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
         unsigned *M = reinterpret_cast<unsigned *>(ws + o_M);                                                            \
         unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
+        unsigned *Tr = reinterpret_cast<unsigned *>(ws + o_Tr);                                                          \
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
         s->last_kernel = "cell-order pipeline (eval_binned_lds)";                                                        \
         hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, td, bp, tab,     \
                            s->lut, prm, n, cell, M, s->bad);                                                             \
-        hipLaunchKernelGGL(bin_rowscan, dim3(bp.cells), dim3(BIN_MAX_CHUNKS), 0, st, bp.chunks, M, tot);                 \
+        hipLaunchKernelGGL(bin_scan_ranges, dim3((bp.cells + 255) / 256, bp.ranges), dim3(256), 0, st, bp, M, Tr);       \
+        hipLaunchKernelGGL(bin_scan_totals, dim3((bp.cells + 255) / 256), dim3(256), 0, st, bp, Tr, tot);                \
         hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
         unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
         unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
@@ -148,10 +154,10 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
-                               start, rec, slot, pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
+                               Tr, start, rec, slot, pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0);             \
+                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0);             \
         bool cs_done = false;                                                                                            \
         if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
             cs_done = true;                                                                                              \
@@ -177,7 +183,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             const size_t lds_u = ((8 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * sizeof(BinOut<T, ND>); \
             HIPCHK(allow_lds(bin_unpermute_wc<T, ND>, lds_u));                                                           \
             hipLaunchKernelGGL((bin_unpermute_wc<T, ND>), dim3(bp.chunks), dim3(1024), lds_u, st, bp, n, cell, slot, M,  \
-                               start, Lb, pbin, tmp, out, ostride);                                                      \
+                               Tr, start, Lb, pbin, tmp, out, ostride);                                                      \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(ugrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
     } break;
