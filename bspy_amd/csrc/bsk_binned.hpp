@@ -11,9 +11,8 @@
 //   bin_count    one workgroup per contiguous chunk of the batch: spans of variables 0 and 1,
 //                domain test, LDS histogram over the cells; writes cell[n] and the chunk's
 //                histogram row M[chunk][cell]
-//   bin_scan_ranges / bin_scan_totals  exclusive scan of every cell's counts over the chunks (ranges of chunks,
-//                then the ranges), cell totals
-//   bin_topscan  one workgroup: exclusive scan of the cell totals
+//   bin_scan_ranges / bin_scan_top  exclusive scan of every cell's counts over the chunks (ranges of chunks, then
+//                the ranges), cell totals and their exclusive scan
 //   bin_scatter  same chunks: slot = start[cell] + M[cell][chunk] + rank inside the chunk (LDS
 //                atomic); writes the record {u..} to rec[slot] and slot[n]
 //   eval_binned_lds  eval_gather's arithmetic on the records in slot order with the cell's
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
 // Scan of the chunk histograms along the chunks, in two steps.
 //   bin_scan_ranges  thread = bin, workgroup = 256 bins x one range of chunks: exclusive prefix inside the range
 //                    (in place), range total -> Tr[range][bin]; rows are read and written coalesced, eight in flight
-//   bin_scan_totals  thread = bin: exclusive prefix over the ranges (in place), bin total -> total[bin]
+//   bin_scan_top     the ranges, then the bins (one workgroup)
 __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigned *__restrict__ M, unsigned *__restrict__ Tr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
@@ -161,24 +160,31 @@ __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigne
     Tr[(size_t)r * bp.cells + i] = run;
 }
 
-__global__ __launch_bounds__(256) void bin_scan_totals(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ total)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= bp.cells) return;
-    unsigned run = 0;
-    for (int r = 0; r < bp.ranges; ++r) { const unsigned v = Tr[(size_t)r * bp.cells + i]; Tr[(size_t)r * bp.cells + i] = run; run += v; }
-    total[i] = run;
-}
-
-// one workgroup: total[0..cells) -> exclusive prefix in start[]
-__global__ __launch_bounds__(1024) void bin_topscan(const int cells, const unsigned *__restrict__ total,
-                                                    unsigned *__restrict__ start)
+// one workgroup, thread = BIN_MAX_CELLS / 1024 consecutive bins: exclusive prefix over the ranges (in place), bin
+// totals, and their exclusive prefix over the bins -> start[]
+__global__ __launch_bounds__(1024) void bin_scan_top(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ start)
 {
     __shared__ unsigned s[1024];
-    const int t = threadIdx.x;
-    const int per = (cells + 1023) / 1024;
+    constexpr int PER = BIN_MAX_CELLS / 1024;
+    const int t = threadIdx.x, cells = bp.cells;
+    const int per = (cells + 1023) / 1024;                  // <= PER
+    unsigned tot[PER];
     unsigned sum = 0;
-    for (int i = 0; i < per; ++i) { const int k = t * per + i; if (k < cells) sum += total[k]; }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        tot[i] = 0;
+        const int k = t * per + i;
+        if (i < per && k < cells) {
+            unsigned run = 0;
+            for (int r = 0; r < bp.ranges; ++r) {
+                const unsigned v = Tr[(size_t)r * cells + k];
+                Tr[(size_t)r * cells + k] = run;
+                run += v;
+            }
+            tot[i] = run;
+            sum += run;
+        }
+    }
     s[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -188,9 +194,10 @@ __global__ __launch_bounds__(1024) void bin_topscan(const int cells, const unsig
         __syncthreads();
     }
     unsigned run = s[t] - sum;
-    for (int i = 0; i < per; ++i) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
         const int k = t * per + i;
-        if (k < cells) { start[k] = run; run += total[k]; }
+        if (i < per && k < cells) { start[k] = run; run += tot[i]; }
     }
 }
 
@@ -247,11 +254,11 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
 // first orders its chunk by bin in LDS can move every run with neighbouring lanes - a run of 6 records is
 // one or two lines instead of six.  The chunk (<= 8192 points) is sized so that its records fit in LDS.
 //   bin_scatter_wc    counts per bin (LDS atomics, rank kept), scan, records into bin order in LDS,
-//                     slot[n] written (coalesced), then rec[...] run by run; also writes the chunk's
-//                     bin-order tables for the way back: Lb[chunk][bin] (first local position of the bin) and
-//                     pbin[lo + p] (bin of local position p)
+//                     lpos[n] = local position of point n (coalesced), then rec[...] run by run; also writes the
+//                     chunk's bin-order tables for the way back: Lb[chunk][bin] (first local position of the bin)
+//                     and pbin[lo + p] (bin of local position p)
 //   bin_unpermute_wc  loads the chunk's runs of `tmp` into LDS the same way, then every point reads its
-//                     result from LDS at Lb[bin] + (slot[n] - run start) and the SoA rows are stored coalesced
+//                     result from LDS at lpos[n] and the SoA rows are stored coalesced
 // ---------------------------------------------------------------------------------------------
 constexpr int WC_PPT = 8;             // points per lane of a 1024-lane workgroup: chunk <= 8192
 constexpr int BIN_MAX_WC_CELLS = 2048; // bins the write-combining kernels hold tables for
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                                                        const unsigned short *__restrict__ cell,
                                                        const unsigned *__restrict__ M, const unsigned *__restrict__ Tr,
                                                        const unsigned *__restrict__ start,
-                                                       BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
+                                                       BinRec<T, NIND> *__restrict__ rec, unsigned short *__restrict__ lpos,
                                                        unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb,
                                                        const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
                                                        const unsigned *__restrict__ glut, const int keyed)
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                 const unsigned p = locb[ck[k]] + rk[k];
                 srec[p] = r[k];
                 sbin[p] = (unsigned short)ck[k];
-                slot[lo + i] = next0[ck[k]] + rk[k];
+                lpos[lo + i] = (unsigned short)p;             // where bin_unpermute_wc finds the point's result in the chunk
             }
         }
         for (int i = threadIdx.x; i < cells; i += blockDim.x) Lb[(size_t)c * cells + i] = locb[i];
@@ -358,8 +365,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
 
 template <typename T, int ND>
 __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const long long N,
-                                                         const unsigned short *__restrict__ cell,
-                                                         const unsigned *__restrict__ slot, const unsigned *__restrict__ M,
+                                                         const unsigned short *__restrict__ lpos, const unsigned *__restrict__ M,
                                                          const unsigned *__restrict__ Tr,
                                                          const unsigned *__restrict__ start, const unsigned *__restrict__ Lb,
                                                          const unsigned short *__restrict__ pbin,
@@ -371,24 +377,76 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
     unsigned *locb = reinterpret_cast<unsigned *>(smem);
     unsigned *next0 = locb + cells;
     BinOut<T, ND> *sout = reinterpret_cast<BinOut<T, ND> *>(smem + ((8 * (size_t)cells + 15) & ~(size_t)15));
-    const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
-    const int cnt = (int)(hi - lo);
-    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
-        locb[i] = Lb[(size_t)blockIdx.x * cells + i];
-        next0[i] = bin_run_start(bp, start, Tr, M, blockIdx.x, i);
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
-        const unsigned b = pbin[lo + p];
-        sout[p] = tmp[next0[b] + ((unsigned)p - locb[b])];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const long long n = lo + i;
-        const unsigned b = cell[n];
-        const BinOut<T, ND> r = sout[locb[b] + (slot[n] - next0[b])];
+    // PERSISTENT, as bin_scatter_wc: while the rows of chunk c are stored, the runs of chunk c + grid are already being
+    // gathered into registers and the run tables of chunk c + 2 grid are on their way.
+    constexpr int NEXT_PPT = (BIN_MAX_WC_CELLS + 1023) / 1024;
+    const int G = (int)gridDim.x;
+    unsigned tl[NEXT_PPT], tn[NEXT_PPT];
+    typedef T gvec __attribute__((ext_vector_type(BinOut<T, ND>::WORDS)));      // (an array of structs ends up in scratch)
+    gvec g[WC_PPT];
+    auto fetch_tables = [&](int c) {
 #pragma unroll
-        for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + n], r.v[dd]);
+        for (int k = 0; k < NEXT_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            tl[k] = i < cells ? Lb[(size_t)c * cells + i] : 0u;
+            tn[k] = i < cells ? bin_run_start(bp, start, Tr, M, c, i) : 0u;
+        }
+    };
+    auto put_tables = [&]() {
+#pragma unroll
+        for (int k = 0; k < NEXT_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cells) { locb[i] = tl[k]; next0[i] = tn[k]; }
+        }
+    };
+    auto gather = [&](int c) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int p0 = k * 1024 + (int)threadIdx.x, p = p0 < cnt ? p0 : cnt - 1;
+            const unsigned b = pbin[lo + p];
+            g[k] = *reinterpret_cast<const gvec *>(&tmp[next0[b] + ((unsigned)p - locb[b])]);
+        }
+    };
+    int c = blockIdx.x;
+    if (c < bp.chunks) {
+        fetch_tables(c);
+        put_tables();
+        __syncthreads();
+        gather(c);
+        if (c + G < bp.chunks) fetch_tables(c + G);
+    }
+    for (; c < bp.chunks; c += G) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int p = k * 1024 + (int)threadIdx.x;
+            if (p < cnt) *reinterpret_cast<gvec *>(&sout[p]) = g[k];
+        }
+        if (c + G < bp.chunks) put_tables();                 // the gather of chunk c has its addresses: its tables may go
+        __syncthreads();
+        unsigned lp[WC_PPT];
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            lp[k] = lpos[lo + (i < cnt ? i : cnt - 1)];
+        }
+        if (c + G < bp.chunks) {
+            gather(c + G);
+            if (c + 2 * G < bp.chunks) fetch_tables(c + 2 * G);
+        }
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cnt) {
+                const gvec r = *reinterpret_cast<const gvec *>(&sout[lp[k]]);
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + lo + i], (T)r[dd]);
+            }
+        }
+        __syncthreads();                                     // sout is free for the next chunk
     }
 }
 

@@ -138,7 +138,6 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         BinRec<T, NIND> *rec = reinterpret_cast<BinRec<T, NIND> *>(ws + o_rec);                                          \
         BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
         unsigned *M = reinterpret_cast<unsigned *>(ws + o_M);                                                            \
-        unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);                                                        \
         unsigned *Tr = reinterpret_cast<unsigned *>(ws + o_Tr);                                                          \
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
@@ -146,15 +145,14 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, td, bp, tab,     \
                            s->lut, prm, n, cell, M, s->bad);                                                             \
         hipLaunchKernelGGL(bin_scan_ranges, dim3((bp.cells + 255) / 256, bp.ranges), dim3(256), 0, st, bp, M, Tr);       \
-        hipLaunchKernelGGL(bin_scan_totals, dim3((bp.cells + 255) / 256), dim3(256), 0, st, bp, Tr, tot);                \
-        hipLaunchKernelGGL(bin_topscan, dim3(1), dim3(1024), 0, st, bp.cells, tot, start);                               \
+        hipLaunchKernelGGL(bin_scan_top, dim3(1), dim3(1024), 0, st, bp, Tr, start);                                     \
         unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
         unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
         if (wc) {                                                                                                        \
             const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
-                               Tr, start, rec, slot, pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
+                               Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
                            st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0);             \
@@ -182,8 +180,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         if (wc) {                                                                                                        \
             const size_t lds_u = ((8 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * sizeof(BinOut<T, ND>); \
             HIPCHK(allow_lds(bin_unpermute_wc<T, ND>, lds_u));                                                           \
-            hipLaunchKernelGGL((bin_unpermute_wc<T, ND>), dim3(bp.chunks), dim3(1024), lds_u, st, bp, n, cell, slot, M,  \
-                               Tr, start, Lb, pbin, tmp, out, ostride);                                                      \
+            hipLaunchKernelGGL((bin_unpermute_wc<T, ND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_u, st, bp, n,    \
+                               reinterpret_cast<const unsigned short *>(slot), M, Tr, start, Lb, pbin, tmp, out, ostride);                                                      \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_unpermute<T, ND>), dim3(ugrid), dim3(256), 0, st, n, slot, tmp, out, ostride);           \
     } break;
