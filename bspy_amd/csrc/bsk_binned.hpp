@@ -603,23 +603,29 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
 //
 // eval_binned_lds gathers every lane's own window from the LDS bundle: 2 KB of LDS reads per cfg5
 // point with ~2-way bank conflicts (lanes of a wave sit in different spans of the third variable).
-// Here a workgroup sorts each tile of 1024 records of a (span0, span1) bin by the span of the THIRD
-// variable in LDS (counting sort, segments padded to multiples of four lanes), so four consecutive
-// lanes always share one cell (span0, span1, span2) and neighbouring lanes mostly do.  The
-// contraction  r[dep] = sum_{ijk} b0_i b1_j b2_k C[i][j][k][dep]  of a 4-lane block then shares its
-// coefficient operand:
-//   MFMA = true   v_mfma_f32_4x4x1_16b_f32: sixteen 4 x 4 outer products per instruction - block b
-//                 accumulates D_b[dep][point] += C_b[step][dep] * w_point[step] over the O^3 window
-//                 steps.  Lane l = 4 b + j feeds the weight of ITS point (B operand) and the
-//                 coefficient of dependent variable j of ITS block's cell (A operand: one 4-byte LDS
-//                 read per step, bundle kept [row][dep][k]); it receives the four dependent variables
-//                 of its own point.  The multiply-adds leave the vector ALU (which forms the O^3
-//                 weights meanwhile): 500 B of LDS reads per point instead of 2 KB.
+// Here a workgroup sorts each tile of ~944 records of a (span0, span1) bin by the span of the THIRD
+// variable in LDS (counting sort on the key the scatter kernel left in the record; segments padded to
+// multiples of four lanes; two barriers per tile), so four consecutive lanes always share one cell
+// (span0, span1, span2) and neighbouring lanes mostly do.  The contraction
+// r[dep] = sum_{ijk} b0_i b1_j b2_k C[i][j][k][dep]  of a 4-lane block then shares its coefficient operand:
+//   MFMA = true   v_mfma_f32_4x4x1_16b_f32: sixteen 4 x 4 outer products per instruction.  The steps k of the
+//                 third variable sit in the ROWS of the product, four at a time, the B operand is the row weight
+//                 b0_i b1_j of the lane's point (cs_contract, see there): per window row (i, j) a lane reads the four
+//                 dependent variables of ONE control point with one aligned ds_read_b128 (bundle kept
+//                 [k][row][dep]: the row offsets are immediates) and feeds one of them to each of ND instructions;
+//                 the reads are issued CS_AHEAD rows before their use.  The lane combines its own partial sums
+//                 with b2 at the end.  375 B of LDS reads per point instead of 2 KB, O^2 + 4 O vector
+//                 multiply-adds per point instead of O^3.
 //   MFMA = false  the same sorted lanes on the vector ALU: eval_gather's arithmetic, every control point
 //                 one 16-byte LDS read that the lanes of a cell share (broadcast, conflict free).
+// The span tables of the bin's first two variables are wave-uniform: read once per bin into scalar registers
+// (SpanTab / basis_regs: basis_fixed's operations in the same order); the third variable's are fetched in one batch.
 // Results go to tmp[slot] of the record's ORIGINAL slot, so bin_unpermute is unchanged.  Summation
-// order differs from eval_gather (one chain over the window per accumulator): results agree to
-// rounding, not bitwise.   LDS: [axis tables][bundle][sorted records][histogram / segment starts]
+// order differs from eval_gather (one chain over the window rows per accumulator): results agree to
+// rounding, not bitwise.   LDS: [axis tables][bundle][sorted records][two histograms, segment starts]
+// Measured steps (10 M cfg5 points): 297 us (first MFMA form: step weights b0 b1 b2 as B operand, 4-byte A reads)
+// -> 260 (row weights) -> 252 (b128 rows read ahead) -> 237 (scalar span tables) -> 228 (two barriers, no register
+// prefetch of the next tile); DESIGN.md section 8.
 // ---------------------------------------------------------------------------------------------
 constexpr int CS_TILE = 1024;           // records sorted at a time (4 per lane of a 256-lane workgroup)
 constexpr int CS_MAX_S2 = 256;          // spans of the third variable the LDS histogram holds
