@@ -188,16 +188,21 @@ __device__ __forceinline__ void uni_issue_window(const unsigned (&ra)[O], int de
     if constexpr (ND >= 3) { if (dep == 2) { uni_issue_window_d<T, O, ND, 2>(ra, c); return; } }
 }
 
-// Closed form of the uniform cubic / linear basis on one span (plain evaluation): the same four
-// polynomials the recursion produces, in 12 instead of 26 operations per variable.
+// Closed forms of the uniform basis of orders 2 .. 5 on one span (plain evaluation): the same polynomials the
+// recursion produces, in 12 (cubic) / 20 (quartic) instead of 26 / 50 operations per variable.
 template <typename T, int O>
 __device__ __forceinline__ void uni_basis_closed(T z, T (&b)[O])
 {
-    static_assert(O == 2 || O == 4, "closed forms for orders 2 and 4");
+    static_assert(O >= 2 && O <= 5, "closed forms for orders 2 .. 5");
     if constexpr (O == 2) {
         b[0] = T(1) - z;
         b[1] = z;
-    } else {
+    } else if constexpr (O == 3) {
+        const T w = T(1) - z;
+        b[0] = (w * T(0.5)) * w;
+        b[2] = (z * T(0.5)) * z;
+        b[1] = (T(1) - z) * z + T(0.5);                     // (-2 z^2 + 2 z + 1) / 2
+    } else if constexpr (O == 4) {
         const T sixth = T(1.0 / 6.0);
         const T w = T(1) - z;
         const T z2 = z * z, w2 = w * w;
@@ -206,6 +211,17 @@ __device__ __forceinline__ void uni_basis_closed(T z, T (&b)[O])
         b[3] = z3 * sixth;
         b[1] = z3 * T(0.5) + (T(2.0 / 3.0) - z2);
         b[2] = z3 * T(-0.5) + (z2 * T(0.5) + (z * T(0.5) + sixth));
+    } else {
+        // quartic: 24 b = (1 - z)^4 | -4 z^4 + 12 z^3 - 6 z^2 - 12 z + 11 | 6 z^4 - 12 z^3 - 6 z^2 + 12 z + 11 |
+        //                 -4 z^4 + 4 z^3 + 6 z^2 + 4 z + 1 | z^4
+        const T c = T(1.0 / 24.0);
+        const T w = T(1) - z;
+        const T w2 = w * w, z2 = z * z;
+        b[0] = (w2 * c) * w2;
+        b[4] = (z2 * c) * z2;
+        b[1] = (((T(-4.0 / 24.0) * z + T(12.0 / 24.0)) * z + T(-6.0 / 24.0)) * z + T(-12.0 / 24.0)) * z + T(11.0 / 24.0);
+        b[2] = (((T(6.0 / 24.0) * z + T(-12.0 / 24.0)) * z + T(-6.0 / 24.0)) * z + T(12.0 / 24.0)) * z + T(11.0 / 24.0);
+        b[3] = (((T(-4.0 / 24.0) * z + T(4.0 / 24.0)) * z + T(6.0 / 24.0)) * z + T(4.0 / 24.0)) * z + c;
     }
 }
 
@@ -521,7 +537,10 @@ __global__ __launch_bounds__(STREAM_BLOCK) void eval_stream_uni(const Desc<T> d,
         uni_spans<T, NIND, DERIV || O == 1>(img_a, un, u, m, z);   // order 1: the basis is 1 whatever u is, so the span of a NaN shows
         T b[NIND][O];
 #pragma unroll
-        for (int iv = 0; iv < NIND; ++iv) uni_basis<T, O, DERIV>(z[iv], DERIV ? wrt.w[iv] : 0, un.inv_h[iv], b[iv]);
+        for (int iv = 0; iv < NIND; ++iv) {
+            if constexpr (!DERIV && O >= 2 && O <= 5) uni_basis_closed<T, O>(z[iv], b[iv]);
+            else uni_basis<T, O, DERIV>(z[iv], DERIV ? wrt.w[iv] : 0, un.inv_h[iv], b[iv]);
+        }
 #pragma unroll
         for (int iv = 0; iv < NIND; ++iv) asm volatile("" : "+v"(unx[iv]));   // prefetched parameters, before the stores
         unsigned caddr = coef_a;
