@@ -31,7 +31,8 @@ namespace bsk {
 
 constexpr int BIN_BLOCK = 512;          // threads per workgroup of the binning kernels
 constexpr int BIN_MAX_CELLS = 8192;     // LDS histogram capacity (32 KB of counters)
-constexpr int BIN_MAX_CHUNKS = 1024;    // one row scan handles this many chunks
+constexpr int BIN_MAX_CHUNKS = 1024;    // chunks of the direct (not write-combining) scatter
+constexpr int BIN_MAX_RANGES = 32;      // ranges of chunks of the histogram scan (bin_scan_ranges / bin_scan_top)
 
 // Cells of the first two variables, coarsened by shifts until they fit BIN_MAX_CELLS.
 struct BinPlan {
@@ -77,13 +78,13 @@ __device__ __forceinline__ int bin_cell(const T *stab, const unsigned *slut, con
 // wait for HBM and have the issue slots - through the bucket table and the knots in global memory (two dependent
 // L1 hits), and carried in the record's spare word.  (In bin_count the same search cost 23 us, in eval_cellsort
 // the bisection was ~85 of its ~360 vector instructions per point.)
-template <typename T, int NIND>
-__device__ __forceinline__ void rec_key(BinRec<T, NIND> &r, const Desc<T> &d, const TileDesc<T> &td, const T *__restrict__ gtab,
-                                        const unsigned *__restrict__ glut)
+template <typename T, int NIND, typename KP, typename LP>
+__device__ __forceinline__ void rec_key(BinRec<T, NIND> &r, const Desc<T> &d, const TileDesc<T> &td, KP knots2, LP lut)
 {
+    // knots2: knots of the third variable; lut: bucket tables, indexed from td.lut_off[2]
     if constexpr (NIND == 3) {
         using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
-        const int key = find_span_lut<T>(gtab + d.off[2], glut, td, 2, d.lo[2], d.ncoef[2], r.v[2]) - d.order[2];
+        const int key = find_span_lut<T>(knots2, lut, td, 2, d.lo[2], d.ncoef[2], r.v[2]) - d.order[2];
         r.v[3] = __builtin_bit_cast(T, (Tag)(unsigned)key);
     }
 }
@@ -111,14 +112,17 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
     for (int i = threadIdx.x; i < bp.cells; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
     const long long lo = (long long)blockIdx.x * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+    // three variables: this kernel reads (and tests against the domain) the two that make the bin; the third is
+    // tested by the scatter kernel, which reads it anyway (8 instead of 12 bytes per point here)
+    constexpr int NV = NIND == 3 ? 2 : NIND;
     for (long long n0 = lo + threadIdx.x; n0 < hi; n0 += (long long)blockDim.x * BIN_ILP) {
-        T u[BIN_ILP][NIND];
+        T u[BIN_ILP][NV];
 #pragma unroll
         for (int k = 0; k < BIN_ILP; ++k) {
             const long long n = n0 + (long long)k * blockDim.x;
             const long long nn = n < hi ? n : hi - 1;
 #pragma unroll
-            for (int iv = 0; iv < NIND; ++iv) u[k][iv] = prm.p[iv][nn];
+            for (int iv = 0; iv < NV; ++iv) u[k][iv] = prm.p[iv][nn];
         }
 #pragma unroll
         for (int k = 0; k < BIN_ILP; ++k) {
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
             if (n < hi) {
                 bool outside = false;
 #pragma unroll
-                for (int iv = 0; iv < NIND; ++iv) outside |= (u[k][iv] < d.lo[iv]) | (u[k][iv] > d.hi[iv]);
+                for (int iv = 0; iv < NV; ++iv) outside |= (u[k][iv] < d.lo[iv]) | (u[k][iv] > d.hi[iv]);
                 if (outside) record_bad(bad, n);
                 const int c = bin_cell<T, O>(stab, slut, d, td, bp, u[k][0], u[k][1]);
                 cell[n] = (unsigned short)c;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigne
 // totals, and their exclusive prefix over the bins -> start[]
 __global__ __launch_bounds__(1024) void bin_scan_top(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ start)
 {
-    __shared__ unsigned s[1024];
+    __shared__ unsigned s[16];
     constexpr int PER = BIN_MAX_CELLS / 1024;
     const int t = threadIdx.x, cells = bp.cells;
     const int per = (cells + 1023) / 1024;                  // <= PER
@@ -175,25 +179,32 @@ __global__ __launch_bounds__(1024) void bin_scan_top(const BinPlan bp, unsigned 
         tot[i] = 0;
         const int k = t * per + i;
         if (i < per && k < cells) {
+            unsigned v[BIN_MAX_RANGES];                       // all loads first: the stores below may alias them
+#pragma unroll
+            for (int r = 0; r < BIN_MAX_RANGES; ++r) v[r] = r < bp.ranges ? Tr[(size_t)r * cells + k] : 0u;
             unsigned run = 0;
-            for (int r = 0; r < bp.ranges; ++r) {
-                const unsigned v = Tr[(size_t)r * cells + k];
-                Tr[(size_t)r * cells + k] = run;
-                run += v;
+#pragma unroll
+            for (int r = 0; r < BIN_MAX_RANGES; ++r) {
+                if (r < bp.ranges) Tr[(size_t)r * cells + k] = run;
+                run += v[r];
             }
             tot[i] = run;
             sum += run;
         }
     }
-    s[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned add = t >= off ? s[t - off] : 0u;
-        __syncthreads();
-        s[t] += add;
-        __syncthreads();
+    // exclusive prefix of `sum` over the 1024 threads: wave scans, then the 16 wave totals
+    const int lane = t & 63, wv = t >> 6;
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
     }
-    unsigned run = s[t] - sum;
+    if (lane == 63) s[wv] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w2 = 0; w2 < wv; ++w2) base += s[w2];
+    unsigned run = base + inc - sum;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int k = t * per + i;
@@ -208,7 +219,8 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
                                                          const unsigned *__restrict__ start,
                                                          BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
                                                          const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
-                                                         const unsigned *__restrict__ glut, const int keyed)
+                                                         const unsigned *__restrict__ glut, const int keyed,
+                                                         unsigned long long *bad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *next = reinterpret_cast<unsigned *>(smem);
@@ -230,12 +242,13 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
         }
         if (keyed) {
 #pragma unroll
-            for (int k = 0; k < BIN_ILP; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
+            for (int k = 0; k < BIN_ILP; ++k) rec_key<T, NIND>(r[k], d, td, gtab + d.off[2], glut);
         }
 #pragma unroll
         for (int k = 0; k < BIN_ILP; ++k) {
             const long long n = n0 + (long long)k * blockDim.x;
             if (n < hi) {
+                if constexpr (NIND == 3) { if ((r[k].v[2] < d.lo[2]) | (r[k].v[2] > d.hi[2])) record_bad(bad, n); }
                 const unsigned p = atomicAdd(&next[w[k]], 1u);
                 rec[p] = r[k];
                 slot[n] = p;
@@ -271,7 +284,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                                                        BinRec<T, NIND> *__restrict__ rec, unsigned short *__restrict__ lpos,
                                                        unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb,
                                                        const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
-                                                       const unsigned *__restrict__ glut, const int keyed)
+                                                       const unsigned *__restrict__ glut, const int keyed,
+                                                       unsigned long long *bad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cells = bp.cells;
@@ -280,6 +294,15 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
     unsigned *next0 = locb + cells;
     BinRec<T, NIND> *srec = reinterpret_cast<BinRec<T, NIND> *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15));
     unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
+    __shared__ unsigned s_wave[16];
+    // keyed == 2: the knots and bucket table of the third variable behind the chunk (two LDS reads per key instead of
+    // two L1 hits)
+    T *skn2 = reinterpret_cast<T *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15) + (((size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2) + 15) & ~(size_t)15));
+    unsigned *slut2 = reinterpret_cast<unsigned *>(skn2 + ((d.nk[NIND == 3 ? 2 : 0] + 3) & ~3));
+    if (keyed == 2) {
+        for (int i = threadIdx.x; i < d.nk[2]; i += blockDim.x) skn2[i] = gtab[d.off[2] + i];
+        for (int i = threadIdx.x; i < td.lut_m[2]; i += blockDim.x) slut2[i] = glut[td.lut_off[2] + i];
+    }
     // PERSISTENT: one workgroup per CU (the chunk fills LDS) walks the chunks blockIdx, blockIdx + grid, ...  The next
     // chunk's points, bins and run starts are fetched into registers BEFORE the store phase of the current one, so that
     // loads and stores of a CU overlap (one chunk per workgroup: load, order, store one after the other, 125 us).
@@ -319,26 +342,42 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < WC_PPT; ++k)
-            if (k * 1024 + (int)threadIdx.x < cnt) rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
-        if (keyed) {
+            if (k * 1024 + (int)threadIdx.x < cnt) {
+                if constexpr (NIND == 3) { if ((r[k].v[2] < d.lo[2]) | (r[k].v[2] > d.hi[2])) record_bad(bad, lo + k * 1024 + (long long)threadIdx.x); }
+                rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
+            }
+        if (keyed == 2) {                                         // span tables of the third variable in LDS
 #pragma unroll
-            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab, glut);
+            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, skn2, slut2 - td.lut_off[NIND == 3 ? 2 : 0]);
+        } else if (keyed) {
+#pragma unroll
+            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab + d.off[NIND == 3 ? 2 : 0], glut);
         }
         __syncthreads();
-        if (threadIdx.x < 64) {                                   // exclusive scan of the bin counts (one wave)
-            const int lane = threadIdx.x;
-            unsigned carry = 0;
-            for (int b0 = 0; b0 < cells; b0 += 64) {
-                const int b = b0 + lane;
-                const unsigned v = b < cells ? lcnt[b] : 0u;
-                unsigned inc = v;
+        {   // exclusive scan of the bin counts: every thread NEXT_PPT consecutive bins, wave scans, 16 wave totals
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            const int per = (cells + 1023) / 1024;
+            unsigned v[NEXT_PPT], sum = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const unsigned o = __shfl_up(inc, off);
-                    if (lane >= off) inc += o;
-                }
-                if (b < cells) locb[b] = carry + inc - v;
-                carry += __shfl(inc, 63);
+            for (int i = 0; i < NEXT_PPT; ++i) {
+                const int b = (int)threadIdx.x * per + i;
+                v[i] = i < per && b < cells ? lcnt[b] : 0u;
+                sum += v[i];
+            }
+            unsigned inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) s_wave[wv] = inc;
+            __syncthreads();
+            unsigned run = inc - sum;
+            for (int w2 = 0; w2 < wv; ++w2) run += s_wave[w2];
+#pragma unroll
+            for (int i = 0; i < NEXT_PPT; ++i) {
+                const int b = (int)threadIdx.x * per + i;
+                if (i < per && b < cells) { locb[b] = run; run += v[i]; }
             }
         }
         __syncthreads();

@@ -87,7 +87,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const int ugrid = env_unp > 0 ? env_unp : 2048;
 
         bp.chunk = (n + bp.chunks - 1) / bp.chunks;
-        bp.ranges = std::min(bp.chunks, 16);
+        bp.ranges = std::min(bp.chunks, BIN_MAX_RANGES);
         bp.rlen = (bp.chunks + bp.ranges - 1) / bp.ranges;
         bp.ranges = (bp.chunks + bp.rlen - 1) / bp.rlen;
         const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
@@ -149,13 +149,18 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
         unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
         if (wc) {                                                                                                        \
-            const size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
+            size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
+            int keyed = cellsort ? 1 : 0;                                                                                \
+            if (keyed && NIND == 3) {    /* span tables of the third variable behind the chunk when LDS has the room */  \
+                const size_t kb = ((lds_s + 15) & ~(size_t)15) + sizeof(T) * (size_t)((d.nk[2] + 3) & ~3) + 4 * (size_t)td.lut_m[2]; \
+                if (kb + 256 <= s->lds_max) { lds_s = kb; keyed = 2; }                                                   \
+            }                                                                                                            \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
-                               Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, cellsort ? 1 : 0);                        \
+                               Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, keyed, s->bad);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0);             \
+                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0, s->bad);             \
         bool cs_done = false;                                                                                            \
         if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
             cs_done = true;                                                                                              \

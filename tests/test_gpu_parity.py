@@ -550,6 +550,13 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
     with pytest.raises(bspy_amd.DomainError) as e:
         t.evaluate(bad)
     assert e.value.index == 123_456
+    # the last variable is tested by the scatter kernel (the count kernel reads only the two that make the bin)
+    bad = [p.copy() for p in pts]
+    bad[-1][77_777] = np.nextafter(dt(knots[-1][ncoef[-1]]), dt(np.inf))
+    bad[0][250_000] = dt(-9.0)
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 77_777
 
 
 @pytest.mark.parametrize("variant,kernel", [("0", "eval_cellsort, MFMA"), ("12", "eval_cellsort, VALU"), ("13", "eval_binned_lds"),
