@@ -423,6 +423,7 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
     unsigned tl[NEXT_PPT], tn[NEXT_PPT];
     typedef T gvec __attribute__((ext_vector_type(BinOut<T, ND>::WORDS)));      // (an array of structs ends up in scratch)
     gvec g[WC_PPT];
+    unsigned lpn[WC_PPT];                                    // local positions of the chunk being gathered
     auto fetch_tables = [&](int c) {
 #pragma unroll
         for (int k = 0; k < NEXT_PPT; ++k) {
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
             const int p0 = k * 1024 + (int)threadIdx.x, p = p0 < cnt ? p0 : cnt - 1;
             const unsigned b = pbin[lo + p];
             g[k] = *reinterpret_cast<const gvec *>(&tmp[next0[b] + ((unsigned)p - locb[b])]);
+            lpn[k] = lpos[lo + p];
         }
     };
     int c = blockIdx.x;
@@ -468,10 +470,7 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
         __syncthreads();
         unsigned lp[WC_PPT];
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
-            const int i = k * 1024 + (int)threadIdx.x;
-            lp[k] = lpos[lo + (i < cnt ? i : cnt - 1)];
-        }
+        for (int k = 0; k < WC_PPT; ++k) lp[k] = lpn[k];      // fetched with the gather, one chunk ago
         if (c + G < bp.chunks) {
             gather(c + G);
             if (c + 2 * G < bp.chunks) fetch_tables(c + 2 * G);
@@ -681,16 +680,18 @@ struct SpanTab {
 };
 
 // basis_fixed's recursion (same operations in the same order: same bits) on a SpanTab
-template <typename T, int O>
+// DERIV = false: plain evaluation, wrt is 0 - straight-line code (the value / derivative branches of every level
+// cost a third of the recursion's instructions in copies where they merge)
+template <typename T, int O, bool DERIV>
 __device__ __forceinline__ void basis_regs(const SpanTab<T, O> &t, T u, int wrt, T (&b)[O])
 {
 #pragma unroll
     for (int k = 0; k < O; ++k) b[k] = T(0);
-    if (wrt >= O) return;
+    if (DERIV && wrt >= O) return;
     b[O - 1] = T(1);
 #pragma unroll
     for (int degree = 1; degree < O; ++degree) {
-        if (degree < O - wrt) {
+        if (!DERIV || degree < O - wrt) {
 #pragma unroll
             for (int j = 0; j < degree; ++j) {
                 const int bi = O - degree + j;
@@ -840,7 +841,7 @@ __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, co
     cs_rows<O, ND, 0>(a_addr, r_addr, b0, b1, b0[0] * b1[0], buf, accg, accr);
 }
 
-template <typename T, int O, int ND, bool MFMA>
+template <typename T, int O, int ND, bool MFMA, bool DERIV = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
@@ -998,10 +999,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
                 T b[3][O];
                 SpanTab<T, O> st2;
                 span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
-                basis_regs<T, O>(st0, r.v[0], wrt.w[0], b[0]);
-                basis_regs<T, O>(st1, r.v[1], wrt.w[1], b[1]);
+                basis_regs<T, O, DERIV>(st0, r.v[0], wrt.w[0], b[0]);
+                basis_regs<T, O, DERIV>(st1, r.v[1], wrt.w[1], b[1]);
                 span_tab_wait<T, O>(st2);
-                basis_regs<T, O>(st2, r.v[2], wrt.w[2], b[2]);
+                basis_regs<T, O, DERIV>(st2, r.v[2], wrt.w[2], b[2]);
                 T res[ND];
                 if constexpr (MFMA) {
                     // The steps m of the THIRD variable go four at a time into the ROWS of the outer product:

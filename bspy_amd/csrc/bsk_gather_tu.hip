@@ -82,6 +82,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             if (wc_chunk < 2048 || (n + wc_chunk - 1) / wc_chunk > 65535) wc_chunk = 0;
         }
         const bool wc = wc_chunk > 0;
+        // (a whole number of rounds of the persistent kernels - 1280 slightly smaller chunks on 256 CUs instead of 1221 -
+        // measured slower: 83 -> 88 and 93 -> 96 us; the shorter runs cost more than the even rounds win)
         if (wc) bp.chunks = (int)((n + wc_chunk - 1) / wc_chunk);
         const int bin_block = env_block > 0 ? env_block : BIN_BLOCK;
         const int ugrid = env_unp > 0 ? env_unp : 2048;
@@ -167,9 +169,17 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             constexpr bool MF = sizeof(T) == 4;                                                                          \
             if (MF && s->variant != 12) {                                                                                \
                 s->last_kernel = "cell-order pipeline (eval_cellsort, MFMA)";                                            \
-                HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF>, cs_lds_mfma));                                             \
-                hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF>), dim3(egrid), dim3(256), cs_lds_mfma, st, d, bp, tab,   \
-                                   aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);                        \
+                bool deriv = false;                                                                                      \
+                for (int iv = 0; iv < 3; ++iv) deriv |= w.w[iv] != 0;                                                    \
+                if (deriv) {                                                                                             \
+                    HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true>, cs_lds_mfma));                                   \
+                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(egrid), dim3(256), cs_lds_mfma, st, d,  \
+                                       bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
+                } else {            /* plain evaluation: the recursion without its derivative branches */              \
+                    HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, !MF>, cs_lds_mfma));                                    \
+                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, !MF>), dim3(egrid), dim3(256), cs_lds_mfma, st, d,   \
+                                       bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
+                }                                                                                                        \
             } else {                                                                                                     \
                 s->last_kernel = "cell-order pipeline (eval_cellsort, VALU)";                                            \
                 HIPCHK(allow_lds(eval_cellsort<T, O, ND, false>, cs_lds_valu));                                          \
