@@ -1118,7 +1118,9 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
     for (int j = 0; j < s->nInd; ++j) {
         Wrt w;
         for (int iv = 0; iv < MAXI; ++iv) w.w[iv] = (iv == j);
+        s->bin_reuse = j > 0;           // cell-order pipeline: the batch is counted, scanned and scattered once
         bsk_status r = dispatch_eval<T>(s, prm, n, out + (long long)j * n, (long long)s->nInd * n, w, st);
+        s->bin_reuse = false;
         if (r != BSK_OK) return r;
     }
     return BSK_OK;

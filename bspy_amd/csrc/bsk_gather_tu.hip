@@ -144,12 +144,13 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         unsigned *start = reinterpret_cast<unsigned *>(ws + o_start);                                                    \
         HIPCHK(allow_lds(bin_count<T, NIND, O>, lds_count));                                                             \
         s->last_kernel = "cell-order pipeline (eval_binned_lds)";                                                        \
+        unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
+        unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
+        if (!s->bin_reuse) {         /* later derivative passes of a jacobian find the batch sorted (dispatch_jac) */    \
         hipLaunchKernelGGL((bin_count<T, NIND, O>), dim3(bp.chunks), dim3(bin_block), lds_count, st, d, td, bp, tab,     \
                            s->lut, prm, n, cell, M, s->bad);                                                             \
         hipLaunchKernelGGL(bin_scan_ranges, dim3((bp.cells + 255) / 256, bp.ranges), dim3(256), 0, st, bp, M, Tr);       \
         hipLaunchKernelGGL(bin_scan_top, dim3(1), dim3(1024), 0, st, bp, Tr, start);                                     \
-        unsigned short *pbin = reinterpret_cast<unsigned short *>(ws + o_pbin);                                          \
-        unsigned *Lb = reinterpret_cast<unsigned *>(ws + o_Lb);                                                          \
         if (wc) {                                                                                                        \
             size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
             int keyed = cellsort ? 1 : 0;                                                                                \
@@ -163,6 +164,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
                            st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0, s->bad);             \
+        }                                                                                                                \
         bool cs_done = false;                                                                                            \
         if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
             cs_done = true;                                                                                              \
