@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
 //
 // eval_binned_lds gathers every lane's own window from the LDS bundle: 2 KB of LDS reads per cfg5
 // point with ~2-way bank conflicts (lanes of a wave sit in different spans of the third variable).
-// Here a workgroup sorts each tile of ~944 records of a (span0, span1) bin by the span of the THIRD
+// Here a workgroup (512 lanes) sorts each tile of ~1970 records (fp64: ~940) of a (span0, span1) bin by the span of the THIRD
 // variable in LDS (counting sort on the key the scatter kernel left in the record; segments padded to
 // multiples of four lanes; two barriers per tile), so four consecutive lanes always share one cell
 // (span0, span1, span2) and neighbouring lanes mostly do.  The contraction
@@ -665,7 +665,10 @@ __global__ __launch_bounds__(256) void eval_binned_lds(const Desc<T> d, const Bi
 // -> 260 (row weights) -> 252 (b128 rows read ahead) -> 237 (scalar span tables) -> 228 (two barriers, no register
 // prefetch of the next tile); DESIGN.md section 8.
 // ---------------------------------------------------------------------------------------------
-constexpr int CS_TILE = 1024;           // records sorted at a time (4 per lane of a 256-lane workgroup)
+constexpr int CS_BLOCK = 512;           // lanes of an eval_cellsort workgroup
+// records sorted at a time: 4 per lane (fp32), 2 per lane (fp64: the 32-byte records must leave room for two workgroups)
+template <typename T>
+__host__ __device__ constexpr int cs_per() { return sizeof(T) == 4 ? 4 : 2; }
 constexpr int CS_MAX_S2 = 256;          // spans of the third variable the LDS histogram holds
 constexpr int CS_AHEAD = 4;             // rows of coefficient reads in flight ahead of the MFMAs that use them
 
@@ -842,7 +845,7 @@ __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, co
 }
 
 template <typename T, int O, int ND, bool MFMA, bool DERIV = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+__global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
                                                      BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
@@ -853,19 +856,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
     const int ncl = d.ncoef[2];
     const int S2 = ncl - d.order[2] + 1;
     constexpr int ROWS = O * O;
+    constexpr int PER = cs_per<T>();                        // records per lane and tile
+    constexpr int TILE_CAP = PER * CS_BLOCK;
     constexpr int DP = MFMA ? 4 : ND;                       // dependent-variable slots of a bundle row
     const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
     const size_t bun_b = (sizeof(T) * (size_t)ROWS * DP * ncl + 15) & ~(size_t)15;
     T *stab = reinterpret_cast<T *>(smem);
     T *bun = reinterpret_cast<T *>(smem + tab_b);
     BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + tab_b + bun_b);
-    unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(CS_TILE + 4 * S2));
+    unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(TILE_CAP + 4 * S2));
     unsigned *segs = hist + 2 * CS_MAX_S2;                  // segment start of every span
     __shared__ int s_first;
     int tile_no = 0;
     // Records per tile: with the padding of its S2 segments (0 .. 3 lanes each, 1.5 on average) a tile should fill the
-    // 16 wave passes of the four waves and not start a 17th that one wave runs while three wait: 1024 - 2 S2 - 8.
-    const int tile = CS_TILE - 2 * S2 - 8 >= CS_TILE / 2 ? CS_TILE - 2 * S2 - 8 : CS_TILE / 2;
+    // wave passes of the workgroup (4 per wave) and not start one more that one wave runs while the others wait.
+    const int tile = TILE_CAP - 2 * S2 - 8 >= TILE_CAP / 2 ? TILE_CAP - 2 * S2 - 8 : TILE_CAP / 2;
     for (int i = threadIdx.x; i < d.tab_len; i += blockDim.x) stab[i] = gtab[i];
     for (int i = threadIdx.x; i < 2 * CS_MAX_S2; i += blockDim.x) hist[i] = 0u;
     const long long per = (N + gridDim.x - 1) / gridDim.x;
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
         span_tab_uniform<T, O>(stab + d.off[1], d.nk[1], q1 + O, st1);
         __syncthreads();                                     // previous bin's readers are done
         // bundle: row r = (i, j) of the bin's O x O control-point rows along the third variable
-        for (int r = wave; r < ROWS; r += 4) {
+        for (int r = wave; r < ROWS; r += CS_BLOCK / 64) {
             const int i = r / O, j = r - i * O;
             const T *__restrict__ src = aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1) * ND;
             if constexpr (MFMA) {
@@ -922,18 +927,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             // the tile's records (their lines were touched one tile ago: L2 hits; keeping them in registers across the
             // evaluation of the previous tile costs 16 registers and, with them, the fourth wave per SIMD)
             typedef T cs_rec4 __attribute__((ext_vector_type(4)));
-            cs_rec4 rc[4];
+            cs_rec4 rc[PER];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long long p = t0 + i * 256 + (long long)threadIdx.x;
+            for (int i = 0; i < PER; ++i) {
+                const long long p = t0 + i * CS_BLOCK + (long long)threadIdx.x;
                 rc[i] = *reinterpret_cast<const cs_rec4 *>(&rec[p < sh ? p : sh - 1]);
             }
             // --- rank inside the span of the third variable
-            int key[4];
-            unsigned rank[4];
+            int key[PER];
+            unsigned rank[PER];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = i * 256 + (int)threadIdx.x;
+            for (int i = 0; i < PER; ++i) {
+                const int idx = i * CS_BLOCK + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
                     key[i] = (int)(unsigned)__builtin_bit_cast(Tag, (T)rc[i][3]);      // found by the scatter kernel (rec_key)
@@ -960,10 +965,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             for (int k = threadIdx.x; k < S2; k += blockDim.x) hn[k] = 0u;
             // --- records into span order; the tag keeps the original position (tmp slot) and the span
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PER; ++i) {
                 if (key[i] >= 0) {
                     cs_rec4 r = rc[i];
-                    const unsigned tag = (unsigned)(i * 256 + (int)threadIdx.x) | ((unsigned)key[i] << 16);
+                    const unsigned tag = (unsigned)(i * CS_BLOCK + (int)threadIdx.x) | ((unsigned)key[i] << 16);
                     r[3] = __builtin_bit_cast(T, (Tag)tag);
                     *reinterpret_cast<cs_rec4 *>(&srec[segs[key[i]] + rank[i]]) = r;
                 }
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             T touch = T(0);
             if (t0 + tile < sh) {
                 const long long p = t0 + tile + (long long)threadIdx.x * (128 / (long long)sizeof(BinRec<T, 3>));
-                if (threadIdx.x < CS_TILE * sizeof(BinRec<T, 3>) / 128 && p < sh) touch = rec[p].v[0];
+                if (threadIdx.x < TILE_CAP * sizeof(BinRec<T, 3>) / 128 && p < sh) touch = rec[p].v[0];
             }
             // padding lanes of a segment: a point inside the same cell, tagged invalid (no store)
             for (int k = threadIdx.x; k < S2; k += blockDim.x) {
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MFMA && O <
             }
             __syncthreads();                                 // (B) tile in span order
             // --- evaluation in span order
-            for (int g = wave * 64; g < total; g += 256) {
+            for (int g = wave * 64; g < total; g += CS_BLOCK) {
                 const int q = g + lane;
                 const bool live = q < total;
                 const BinRec<T, 3> r = srec[live ? q : total - 1];

@@ -113,6 +113,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const T *tab = static_cast<const T *>(s->tab);
         const T *aos = static_cast<const T *>(s->coef_aos);
         const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
+        // eval_cellsort: two 512-lane workgroups per CU, two rounds
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((n + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * 4));
         // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
         const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
         const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
@@ -123,7 +125,7 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         size_t cs_lds_mfma = 0, cs_lds_valu = 0;
         if constexpr (NIND == 3 && !MIXED) {
             const int S2 = s->ncoef[2] - s->order[2] + 1;
-            const size_t rec_b = 4 * sizeof(T) * (size_t)(CS_TILE + 4 * S2) + sizeof(unsigned) * (size_t)(3 * CS_MAX_S2 + 4);
+            const size_t rec_b = 4 * sizeof(T) * (size_t)(cs_per<T>() * CS_BLOCK + 4 * S2) + sizeof(unsigned) * (size_t)(3 * CS_MAX_S2 + 4);
             auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
             cs_lds_mfma = tab_b + up16(sizeof(T) * (size_t)O * O * 4 * s->ncoef[2]) + rec_b;
             cs_lds_valu = tab_b + up16(sizeof(T) * (size_t)O * O * s->nDep * s->ncoef[2]) + rec_b;
@@ -175,17 +177,17 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
                 for (int iv = 0; iv < 3; ++iv) deriv |= w.w[iv] != 0;                                                    \
                 if (deriv) {                                                                                             \
                     HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true>, cs_lds_mfma));                                   \
-                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(egrid), dim3(256), cs_lds_mfma, st, d,  \
+                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,  \
                                        bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
                 } else {            /* plain evaluation: the recursion without its derivative branches */              \
                     HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, !MF>, cs_lds_mfma));                                    \
-                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, !MF>), dim3(egrid), dim3(256), cs_lds_mfma, st, d,   \
+                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, !MF>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,   \
                                        bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
                 }                                                                                                        \
             } else {                                                                                                     \
                 s->last_kernel = "cell-order pipeline (eval_cellsort, VALU)";                                            \
                 HIPCHK(allow_lds(eval_cellsort<T, O, ND, false>, cs_lds_valu));                                          \
-                hipLaunchKernelGGL((eval_cellsort<T, O, ND, false>), dim3(egrid), dim3(256), cs_lds_valu, st, d, bp,     \
+                hipLaunchKernelGGL((eval_cellsort<T, O, ND, false>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_valu, st, d, bp, \
                                    tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);                   \
             }                                                                                                            \
         }                                                                                                                \
