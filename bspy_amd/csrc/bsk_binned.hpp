@@ -32,7 +32,7 @@ namespace bsk {
 constexpr int BIN_BLOCK = 512;          // threads per workgroup of the binning kernels
 constexpr int BIN_MAX_CELLS = 8192;     // LDS histogram capacity (32 KB of counters)
 constexpr int BIN_MAX_CHUNKS = 1024;    // chunks of the direct (not write-combining) scatter
-constexpr int BIN_MAX_RANGES = 32;      // ranges of chunks of the histogram scan (bin_scan_ranges / bin_scan_top)
+constexpr int BIN_MAX_RANGES = 16;      // ranges of chunks of the histogram scan (bin_scan_ranges / bin_scan_top)
 
 // Cells of the first two variables, coarsened by shifts until they fit BIN_MAX_CELLS.
 struct BinPlan {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
 
 // Scan of the chunk histograms along the chunks, in two steps.
 //   bin_scan_ranges  thread = bin, workgroup = 256 bins x one range of chunks: exclusive prefix inside the range
-//                    (in place), range total -> Tr[range][bin]; rows are read and written coalesced, eight in flight
+//                    (in place), range total -> Tr[range][bin]; rows are read and written coalesced, sixteen in flight
 //   bin_scan_top     the ranges, then the bins (one workgroup)
 __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigned *__restrict__ M, unsigned *__restrict__ Tr)
 {
@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigne
     const int c0 = r * bp.rlen, c1 = c0 + bp.rlen < bp.chunks ? c0 + bp.rlen : bp.chunks;
     unsigned run = 0;
     int c = c0;
-    for (; c + 8 <= c1; c += 8) {
-        unsigned v[8];
+    for (; c + 16 <= c1; c += 16) {
+        unsigned v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = M[(size_t)(c + k) * bp.cells + i];
+        for (int k = 0; k < 16; ++k) v[k] = M[(size_t)(c + k) * bp.cells + i];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { M[(size_t)(c + k) * bp.cells + i] = run; run += v[k]; }
+        for (int k = 0; k < 16; ++k) { M[(size_t)(c + k) * bp.cells + i] = run; run += v[k]; }
     }
     for (; c < c1; ++c) { const unsigned v = M[(size_t)c * bp.cells + i]; M[(size_t)c * bp.cells + i] = run; run += v; }
     Tr[(size_t)r * bp.cells + i] = run;
