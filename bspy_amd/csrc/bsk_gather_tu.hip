@@ -114,7 +114,8 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const T *aos = static_cast<const T *>(s->coef_aos);
         const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
         // eval_cellsort: two 512-lane workgroups per CU, two rounds
-        const int cgrid = (int)std::max<long long>(1, std::min<long long>((n + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * 4));
+        static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;                 // measurement knob: workgroups per CU
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((n + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : 4)));
         // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
         const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
         const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;
