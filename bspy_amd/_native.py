@@ -19,15 +19,18 @@ BSK_HOST, BSK_DEVICE = 0, 1
 BSK_OK, BSK_ERR_INVALID, BSK_ERR_DOMAIN, BSK_ERR_HIP, BSK_ERR_NO_DEVICE, BSK_ERR_UNSUPPORTED = range(6)
 BSK_MAX_NIND, BSK_MAX_ORDER = 8, 16
 
-# every symbol include/bspy_amd.h declares (tests check the library exports them all)
-SYMBOLS = (
+# every symbol of the product ABI in include/bspy_amd.h (tests check the library exports them all) ...
+PRODUCT_SYMBOLS = (
     "bsk_version", "bsk_last_error", "bsk_device_count",
     "bsk_spline_create", "bsk_spline_update", "bsk_spline_destroy",
     "bsk_evaluate", "bsk_jacobian", "bsk_normal", "bsk_curvature", "bsk_evaluate_grid", "bsk_tessellate",
-    "bsk_domain_status", "bsk_bspline_values", "bsk_last_kernel", "bsk_debug_probe",
+    "bsk_domain_status", "bsk_bspline_values", "bsk_last_kernel",
     "bsk_multi_create", "bsk_multi_destroy", "bsk_multi_shard_plan", "bsk_multi_stream", "bsk_multi_evaluate",
     "bsk_multi_jacobian",
 )
+# ... and the measurement hooks of its BSK_INTERNAL section (bench.py, tools/: not used by the product path)
+INTERNAL_SYMBOLS = ("bsk_debug_probe", "bsk_debug_stage_times")
+SYMBOLS = PRODUCT_SYMBOLS + INTERNAL_SYMBOLS
 
 
 class NativeLibraryError(RuntimeError):
@@ -108,6 +111,8 @@ def lib():
     L.bsk_last_kernel.argtypes = [_vp]
     L.bsk_last_kernel.restype = ctypes.c_char_p
     L.bsk_debug_probe.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i64, _vp, _vp, _i64, _vp, _vp]
+    L.bsk_debug_stage_times.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p),
+                                        ctypes.c_int, _ip]
     for name in SYMBOLS:
         if name not in ("bsk_version", "bsk_last_error", "bsk_last_kernel"):
             getattr(L, name).restype = ctypes.c_int

@@ -303,6 +303,8 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->pin = nullptr;
     pipe_destroy(s->pipe);
     s->pipe = nullptr;
+    for (hipEvent_t &e : s->stage_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
     delete s;
     return BSK_OK;
 }
@@ -491,7 +493,14 @@ static bool axis_is_uniform(const T *k, int order, int ncoef, bool &clamp_lo, bo
     const long double lo = k[order - 1], hi = k[ncoef];
     if (!(hi > lo) || ns < 1) return false;
     const long double h = (hi - lo) / ns;
-    const long double tol = (sizeof(T) == 8 ? 1024.0L : 32.0L) * std::numeric_limits<T>::epsilon() * h;
+    // "Equally spaced" = every stored knot is lo + j h up to the ROUNDING of the stored value (4 ulp of the largest
+    // knot: np.linspace is within 1.5), and that rounding is small against the span (1024 ulp of h: the uniform
+    // kernels form alpha from the nominal width, the reference from the stored knots; a deviation d of a knot moves
+    // the result by d / h).  A user's perturbation of a few hundred ulp of h is NOT rounding: such knots keep the
+    // general kernels (test_uniform_path_declines_perturbed_knots).
+    const long double eps = std::numeric_limits<T>::epsilon();
+    const long double mag = std::max(std::fabs(lo), std::fabs(hi));
+    const long double tol = std::min((sizeof(T) == 8 ? 1024.0L : 32.0L) * eps * h, 4.0L * eps * mag);
     for (int j = 0; j <= ns; ++j)
         if (std::fabs((long double)k[order - 1 + j] - (lo + j * h)) > tol) return false;
     auto side = [&](bool low, bool &clamped) {
@@ -2174,6 +2183,27 @@ extern "C" bsk_status bsk_bspline_values(bsk_dtype dtype, int device, const void
 // bytes per lane, blocks_per_cu workgroups per CU, lds_bytes of dynamic LDS each.  Device
 // pointers, fp64.  Used by tools/ to measure the memory-side floor; not an evaluation call.
 extern "C" const char *bsk_last_kernel(bsk_spline s) { return s ? s->last_kernel : ""; }
+
+// Per-kernel times of the most recent multi-kernel pipeline call on this handle (the cell-order pipeline): `enable`
+// switches the recording of an event behind every kernel on or off for the FOLLOWING calls; with ms / names it
+// returns the durations of the last recorded call (after synchronising its last event).
+extern "C" bsk_status bsk_debug_stage_times(bsk_spline s, int enable, float *ms, const char **names, int cap, int *count)
+{
+    if (!s) return fail(BSK_ERR_INVALID, "spline is NULL");
+    int n = 0;
+    if (ms && names && count && s->stage_count > 1) {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipEventSynchronize(s->stage_ev[s->stage_count - 1]));
+        for (int i = 0; i + 1 < s->stage_count && n < cap; ++i, ++n) {
+            HIPCHK(hipEventElapsedTime(&ms[n], s->stage_ev[i], s->stage_ev[i + 1]));
+            names[n] = s->stage_name[i + 1];
+        }
+    }
+    if (count) *count = n;
+    s->stage_timing = enable != 0;
+    if (!enable) s->stage_count = 0;
+    return BSK_OK;
+}
 
 extern "C" bsk_status bsk_debug_probe(bsk_spline s, int mode, int blocks_per_cu, int threads, int64_t lds_bytes,
                                       const void *u, const void *v, int64_t n, void *out, void *stream)

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
         __syncthreads();
         gather(c);
         if (c + G < bp.chunks) fetch_tables(c + G);
+        __syncthreads();        // every wave has formed its addresses from the tables of chunk c before iteration 0 replaces them
     }
     for (; c < bp.chunks; c += G) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
@@ -476,6 +477,317 @@ __global__ __launch_bounds__(1024) void bin_unpermute_wc(const BinPlan bp, const
             gather(c + G);
             if (c + 2 * G < bp.chunks) fetch_tables(c + 2 * G);
         }
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cnt) {
+                const gvec r = *reinterpret_cast<const gvec *>(&sout[lp[k]]);
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) nt_store(&out[dd * ostride + lo + i], (T)r[dd]);
+            }
+        }
+        __syncthreads();                                     // sout is free for the next chunk
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 3: the sort side of the three-variable pipeline (eval_cellsort) without chunk histograms in memory.
+//
+// Round 2 kept a [chunk][bin] matrix of counts (bin_count), scanned it along the chunks (two kernels) and read
+// it back in the scatter AND in the un-permute, which also needed two more per-point arrays (pbin, and the bin of
+// every point from bin_count) to find the runs of `tmp` again: 49 us of counting / scanning and 91 us of gathering
+// runs per 10 M cfg5 points.  Here
+//   bin_totals            persistent, 16-byte loads: bins of the whole batch counted in one LDS histogram per
+//                         workgroup and added to tot[] once per workgroup (contiguous no-return atomics); the LAST
+//                         workgroup to finish (ticket) scans tot[] -> start[], fill[] = start[]
+//   bin_scatter_tag       persistent over the chunks: bin and span key computed here (the batch is read once, no
+//                         cell[] array); a chunk's run of bin b starts at atomicAdd(fill[b], count) - runs of
+//                         different chunks land in ARRIVAL order: the slot of a record is not deterministic, its
+//                         result is; the record's spare word carries  dest | key << dest_bits,  dest = the
+//                         record's position in CHUNK order (lo + local position in the chunk ordered by bin)
+//   eval_cellsort         stores a record's result at tmp[dest]: the evaluation is issue bound, its scattered
+//                         16-byte stores (runs of ~6 neighbours, as the scatter's) are hidden
+//   bin_unpermute_stream  chunk c: tmp[lo .. hi) is CONTIGUOUS - streamed into LDS, then
+//                         out[dep][lo + i] = sout[lpos[lo + i]][dep]: no run tables, no gather
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SpanLds {                        // knots and bucket tables of up to three variables in LDS
+    const T *kn[3];
+    const unsigned *lut;
+};
+
+template <typename T, int NV>
+__host__ __device__ __forceinline__ size_t span_lds_bytes(const Desc<T> &d, const TileDesc<T> &td)
+{
+    size_t b = 0;
+    for (int iv = 0; iv < NV; ++iv) b += sizeof(T) * (size_t)((d.nk[iv] + 3) & ~3);
+    return b + 4 * (size_t)((td.lut_len + 3) & ~3);
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ SpanLds<T> span_lds_stage(char *base, const Desc<T> &d, const TileDesc<T> &td, const T *__restrict__ gtab,
+                                                     const unsigned *__restrict__ glut)
+{
+    SpanLds<T> sl;
+    T *k = reinterpret_cast<T *>(base);
+    for (int iv = 0; iv < 3; ++iv) sl.kn[iv] = k;
+    for (int iv = 0; iv < NV; ++iv) {
+        sl.kn[iv] = k;
+        for (int i = threadIdx.x; i < d.nk[iv]; i += blockDim.x) k[i] = gtab[d.off[iv] + i];
+        k += (d.nk[iv] + 3) & ~3;
+    }
+    unsigned *l = reinterpret_cast<unsigned *>(k);
+    for (int i = threadIdx.x; i < td.lut_len; i += blockDim.x) l[i] = glut[i];
+    sl.lut = l;
+    return sl;
+}
+
+template <typename T>
+__device__ __forceinline__ int bin_of(const SpanLds<T> &sl, const Desc<T> &d, const TileDesc<T> &td, const BinPlan &bp, T u0, T u1)
+{
+    const int i0 = find_span_lut<T>(sl.kn[0], sl.lut, td, 0, d.lo[0], d.ncoef[0], u0) - d.order[0];
+    const int i1 = find_span_lut<T>(sl.kn[1], sl.lut, td, 1, d.lo[1], d.ncoef[1], u1) - d.order[1];
+    return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
+}
+
+// exclusive prefix over `cells` values held `per` consecutive ones per thread of a 1024-lane workgroup (v[i] of bin
+// t * per + i); returns the prefix of the thread's first bin.  s_wave: 16 words of LDS.  One barrier inside.
+template <int PER>
+__device__ __forceinline__ unsigned block_excl_scan(const unsigned (&v)[PER], unsigned *s_wave)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) sum += v[i];
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    unsigned run = inc - sum;
+    for (int w2 = 0; w2 < wv; ++w2) run += s_wave[w2];
+    return run;
+}
+
+// LDS: [knots + bucket tables of variables 0, 1][cells x u32]
+template <typename T>
+__global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDesc<T> td, const BinPlan bp,
+                                                   const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                   const Params<T> prm, const long long N, unsigned *__restrict__ tot,
+                                                   unsigned *__restrict__ start, unsigned *__restrict__ fill,
+                                                   unsigned *__restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_wave[16];
+    __shared__ int s_last;
+    const SpanLds<T> sl = span_lds_stage<T, 2>(smem, d, td, gtab, glut);
+    unsigned *hist = reinterpret_cast<unsigned *>(smem + ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15));
+    const int cells = bp.cells;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+    const bool aligned = ((reinterpret_cast<size_t>(prm.p[0]) | reinterpret_cast<size_t>(prm.p[1])) & 15) == 0;
+    const long long nvec = aligned ? N / V : 0;                 // 16-byte groups; the rest (and misaligned batches) one by one
+    for (long long g = gtid; g < nvec; g += 2 * gstride) {
+        const long long g1 = g + gstride;
+        const bool two = g1 < nvec;
+        const vecT a0 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[0]) + g);
+        const vecT b0 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[1]) + g);
+        const vecT a1 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[0]) + (two ? g1 : g));
+        const vecT b1 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[1]) + (two ? g1 : g));
+#pragma unroll
+        for (int k = 0; k < V; ++k) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, a0[k], b0[k])], 1u);
+        if (two) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, a1[k], b1[k])], 1u);
+        }
+    }
+    for (long long n = nvec * V + gtid; n < N; n += gstride) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, prm.p[0][n], prm.p[1][n])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        const unsigned h = hist[i];
+        if (h) atomicAdd(&tot[i], h);                           // device-scope adds: complete before this workgroup's ticket
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup: every other workgroup's adds came before its ticket.  The totals are read with atomics too
+    // (an atomic read-and-reset: served where the adds were made, never from a stale line of this XCD's L2).
+    constexpr int PER = BIN_MAX_CELLS / 1024;
+    const int per = (cells + 1023) / 1024;
+    unsigned v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = (int)threadIdx.x * per + i;
+        v[i] = (i < per && k < cells) ? atomicExch(&tot[k], 0u) : 0u;
+    }
+    unsigned run = block_excl_scan<PER>(v, s_wave);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int k = (int)threadIdx.x * per + i;
+        if (i < per && k < cells) { start[k] = run; fill[k] = run; run += v[i]; }
+    }
+    if (threadIdx.x == 0) atomicExch(done, 0u);
+}
+
+// dest | key << dest_bits in the record's spare word (fp64 records: the low 32 bits of it)
+template <typename T>
+__device__ __forceinline__ T tag_word(unsigned tag)
+{
+    using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+    return __builtin_bit_cast(T, (Tag)tag);
+}
+template <typename T>
+__device__ __forceinline__ unsigned word_tag(T w)
+{
+    using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+    return (unsigned)__builtin_bit_cast(Tag, w);
+}
+
+// LDS: [counts -> run starts: cells x u32][local bin starts: cells x u32][records: chunk x 16 / 32 B][bins: chunk x u16]
+//      [knots + bucket tables of the three variables]
+template <typename T>
+__global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const Params<T> prm, const long long N, const long long base,
+                                                        unsigned *__restrict__ fill, BinRec<T, 3> *__restrict__ rec,
+                                                        unsigned short *__restrict__ lpos, const Desc<T> d, const TileDesc<T> td,
+                                                        const T *__restrict__ gtab, const unsigned *__restrict__ glut,
+                                                        const int dest_bits, unsigned long long *bad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_wave[16];
+    const int cells = bp.cells;
+    unsigned *lcnt = reinterpret_cast<unsigned *>(smem);     // counts of the chunk; after the scan: global start of the bin's run
+    unsigned *locb = lcnt + cells;
+    BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + ((8 * (size_t)cells + 15) & ~(size_t)15));
+    unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
+    char *tabs = smem + ((8 * (size_t)cells + 15) & ~(size_t)15) + (((size_t)bp.chunk * (sizeof(BinRec<T, 3>) + 2) + 15) & ~(size_t)15);
+    const SpanLds<T> sl = span_lds_stage<T, 3>(tabs, d, td, gtab, glut);
+    constexpr int NEXT_PPT = (BIN_MAX_WC_CELLS + 1023) / 1024;
+    const int per = (cells + 1023) / 1024;
+    T pu[WC_PPT], pv[WC_PPT], pw[WC_PPT];
+    auto fetch = [&](int c) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            const long long nn = lo + (i < cnt ? i : cnt - 1);
+            pu[k] = __builtin_nontemporal_load(&prm.p[0][nn]);
+            pv[k] = __builtin_nontemporal_load(&prm.p[1][nn]);
+            pw[k] = __builtin_nontemporal_load(&prm.p[2][nn]);
+        }
+    };
+    int c = blockIdx.x;
+    if (c < bp.chunks) fetch(c);
+    for (; c < bp.chunks; c += gridDim.x) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+        __syncthreads();                                          // the previous chunk's store phase is done with LDS (and the tables are staged)
+        for (int i = threadIdx.x; i < cells; i += blockDim.x) lcnt[i] = 0u;
+        __syncthreads();
+        unsigned ck[WC_PPT], rk[WC_PPT], tg[WC_PPT];
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            ck[k] = 0u; rk[k] = 0u; tg[k] = 0u;
+            if (k * 1024 + (int)threadIdx.x < cnt) {
+                const bool outside = (pu[k] < d.lo[0]) | (pu[k] > d.hi[0]) | (pv[k] < d.lo[1]) | (pv[k] > d.hi[1]) | (pw[k] < d.lo[2]) | (pw[k] > d.hi[2]);
+                if (outside) record_bad(bad, base + lo + k * 1024 + (long long)threadIdx.x);
+                ck[k] = (unsigned)bin_of<T>(sl, d, td, bp, pu[k], pv[k]);
+                tg[k] = (unsigned)(find_span_lut<T>(sl.kn[2], sl.lut, td, 2, d.lo[2], d.ncoef[2], pw[k]) - d.order[2]) << dest_bits;
+                rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the bin counts -> first local position of every bin; the bin's run in `rec` is claimed with
+        // ONE returned atomic per bin and chunk (contiguous addresses per wave instruction)
+        unsigned v[NEXT_PPT], g[NEXT_PPT];
+#pragma unroll
+        for (int i = 0; i < NEXT_PPT; ++i) {
+            const int b = (int)threadIdx.x * per + i;
+            v[i] = i < per && b < cells ? lcnt[b] : 0u;
+        }
+        unsigned run = block_excl_scan<NEXT_PPT>(v, s_wave);
+#pragma unroll
+        for (int i = 0; i < NEXT_PPT; ++i) {
+            const int b = (int)threadIdx.x * per + i;
+            g[i] = 0u;
+            if (i < per && b < cells) {
+                locb[b] = run;
+                run += v[i];
+                if (v[i]) g[i] = atomicAdd(&fill[b], v[i]);
+            }
+        }
+        __syncthreads();                                          // local bin starts complete; every count has been read
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int i = k * 1024 + (int)threadIdx.x;
+            if (i < cnt) {
+                const unsigned p = locb[ck[k]] + rk[k];
+                BinRec<T, 3> r;
+                r.v[0] = pu[k]; r.v[1] = pv[k]; r.v[2] = pw[k];
+                r.v[3] = tag_word<T>((unsigned)(lo + p) | tg[k]);   // where bin_unpermute_stream finds the result, and the span key
+                srec[p] = r;
+                sbin[p] = (unsigned short)ck[k];
+                lpos[lo + i] = (unsigned short)p;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NEXT_PPT; ++i) {
+            const int b = (int)threadIdx.x * per + i;
+            if (i < per && b < cells) lcnt[b] = g[i];             // the counts are dead: the slot holds the run's global start now
+        }
+        if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);     // in flight during the store phase
+        __syncthreads();
+        for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+            const unsigned b = sbin[p];
+            rec[lcnt[b] + ((unsigned)p - locb[b])] = srec[p];
+        }
+    }
+}
+
+template <typename T, int ND>
+__global__ __launch_bounds__(1024) void bin_unpermute_stream(const BinPlan bp, const long long N, const unsigned short *__restrict__ lpos,
+                                                             const BinOut<T, ND> *__restrict__ tmp, T *__restrict__ out,
+                                                             const long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BinOut<T, ND> *sout = reinterpret_cast<BinOut<T, ND> *>(smem);
+    typedef T gvec __attribute__((ext_vector_type(BinOut<T, ND>::WORDS)));
+    const int G = (int)gridDim.x;
+    gvec g[WC_PPT];
+    unsigned lpn[WC_PPT];
+    auto fetch = [&](int c) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int p0 = k * 1024 + (int)threadIdx.x, p = p0 < cnt ? p0 : cnt - 1;
+            g[k] = *reinterpret_cast<const gvec *>(&tmp[lo + p]);
+            lpn[k] = lpos[lo + p];
+        }
+    };
+    int c = blockIdx.x;
+    if (c < bp.chunks) fetch(c);
+    for (; c < bp.chunks; c += G) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) {
+            const int p = k * 1024 + (int)threadIdx.x;
+            if (p < cnt) *reinterpret_cast<gvec *>(&sout[p]) = g[k];
+        }
+        unsigned lp[WC_PPT];
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) lp[k] = lpn[k];
+        __syncthreads();
+        if (c + G < bp.chunks) fetch(c + G);                   // the next chunk streams in while this one's rows are stored
 #pragma unroll
         for (int k = 0; k < WC_PPT; ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
@@ -849,7 +1161,7 @@ template <typename T, int O, int ND, bool MFMA, bool DERIV = true>
 __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
-                                                     BinOut<T, ND> *__restrict__ tmp, const Wrt wrt)
+                                                     BinOut<T, ND> *__restrict__ tmp, const Wrt wrt, const int dest_bits)
 {
     static_assert(!MFMA || (sizeof(T) == 4 && ND <= 4), "the 4x4x1 fp32 MFMA form");
     static_assert(sizeof(BinRec<T, 3>) == 4 * sizeof(T), "record = u, v, w, tag");
@@ -918,7 +1230,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 for (int e = lane; e < ncl * ND; e += 64) bun[(size_t)r * ncl * ND + e] = src[e];
             }
         }
-        using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+        const unsigned dest_mask = (1u << dest_bits) - 1u;      // record tag = dest | span key << dest_bits (bin_scatter_tag)
         for (long long t0 = sl; t0 < sh; t0 += tile) {
             const int cnt = (int)((sh - t0) < tile ? (sh - t0) : tile);
             // Two barriers per tile.  The histograms alternate: this tile counts in `hc` (zeroed one tile ago), and
@@ -943,7 +1255,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 const int idx = i * CS_BLOCK + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
-                    key[i] = (int)(unsigned)__builtin_bit_cast(Tag, (T)rc[i][3]);      // found by the scatter kernel (rec_key)
+                    key[i] = (int)(word_tag<T>((T)rc[i][3]) >> dest_bits);             // found by the scatter kernel
                     rank[i] = atomicAdd(&hc[key[i]], 1u);
                 }
             }
@@ -965,15 +1277,10 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
             }
             const int total = (int)__builtin_amdgcn_readfirstlane((int)carry);
             for (int k = threadIdx.x; k < S2; k += blockDim.x) hn[k] = 0u;
-            // --- records into span order; the tag keeps the original position (tmp slot) and the span
+            // --- records into span order (the tag travels with the record: destination of the result and the span)
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                if (key[i] >= 0) {
-                    cs_rec4 r = rc[i];
-                    const unsigned tag = (unsigned)(i * CS_BLOCK + (int)threadIdx.x) | ((unsigned)key[i] << 16);
-                    r[3] = __builtin_bit_cast(T, (Tag)tag);
-                    *reinterpret_cast<cs_rec4 *>(&srec[segs[key[i]] + rank[i]]) = r;
-                }
+                if (key[i] >= 0) *reinterpret_cast<cs_rec4 *>(&srec[segs[key[i]] + rank[i]]) = rc[i];
             }
             // touch the lines of the next tile's records (one dword per 128-byte line), consumed after the evaluation
             T touch = T(0);
@@ -989,8 +1296,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     r.v[0] = d.lo[0];
                     r.v[1] = d.lo[1];
                     r.v[2] = tab2[k + d.order[2] - 1];        // left knot of span k: inside the cell
-                    const unsigned tag = 0xffffu | ((unsigned)k << 16);
-                    r.v[3] = __builtin_bit_cast(T, (Tag)tag);
+                    r.v[3] = tag_word<T>(dest_mask | ((unsigned)k << dest_bits));
                     for (unsigned p = have; p < want; ++p) srec[segs[k] + p] = r;
                 }
             }
@@ -1000,9 +1306,9 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 const int q = g + lane;
                 const bool live = q < total;
                 const BinRec<T, 3> r = srec[live ? q : total - 1];
-                const unsigned tag = (unsigned)__builtin_bit_cast(Tag, r.v[3]);
-                const int ix2 = (int)(tag >> 16);
-                const unsigned idx = tag & 0xffffu;
+                const unsigned tag = word_tag<T>(r.v[3]);
+                const int ix2 = (int)(tag >> dest_bits);
+                const unsigned dest = tag & dest_mask;
                 T b[3][O];
                 SpanTab<T, O> st2;
                 span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
@@ -1046,11 +1352,11 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     int pad[3] = {0, 0, 0};
                     window_contract<T, 3, O, ND, false>(bun + (long long)ix2 * ND, O * ncl, ncl, pad, b, res);
                 }
-                if (live && idx != 0xffffu) {
+                if (live && dest != dest_mask) {
                     BinOut<T, ND> o;
 #pragma unroll
                     for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);
-                    tmp[t0 + idx] = o;        // (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
+                    tmp[dest] = o;            // chunk order (bin_unpermute_stream); (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
                 }
             }
             asm volatile("" :: "v"(touch));

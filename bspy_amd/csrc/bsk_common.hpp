@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define BSK_INTERNAL 1      // the library defines its measurement hooks too
 #include "../../include/bspy_amd.h"
 
 namespace bsk {

@@ -41,6 +41,113 @@ constexpr long long BIN_MIN_POINTS = 1 << 18;
 #define BIN_CHUNK_POINTS 8192
 #endif
 
+// Three variables of one order on an L2-resident table (BASELINE cfg5): the round-3 pipeline of bsk_binned.hpp,
+//   bin_totals -> bin_scatter_tag -> eval_cellsort -> bin_unpermute_stream
+// (4 launches; round 2: 6).  A record's tag holds its destination in chunk order and its span key in 32 bits, so a
+// launch takes at most 2^26 - 1 points (span keys < 64) or 2^24 - 1 (< 256): larger batches run piece by piece.
+template <typename T, int O>
+static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Params<T> &prm, long long n, T *out, long long ostride,
+                                           const Wrt &w, hipStream_t st, size_t cs_lds_mfma, size_t cs_lds_valu)
+{
+    const Desc<T> &d = desc_of<T>(s);
+    const TileDesc<T> &td = tile_of<T>(s);
+    const int S2 = s->ncoef[2] - s->order[2] + 1;
+    const int dest_bits = S2 <= 64 ? 26 : 24;
+    const long long piece_max = (((1ll << dest_bits) - 1) / 1024) * 1024;
+    const long long pieces = (n + piece_max - 1) / piece_max;
+    const long long piece = std::min(n, (((n + pieces - 1) / pieces) + 1023) / 1024 * 1024);
+    // chunk of the scatter / un-permute: records (+ a 16-bit bin each) beside two bin tables and the span tables
+    const size_t tabs_b = (span_lds_bytes<T, 3>(d, td) + 15) & ~(size_t)15;
+    const size_t bins_b = (8 * (size_t)bp.cells + 15) & ~(size_t)15;
+    if (bins_b + tabs_b + 1024 > s->lds_max || bp.cells > BIN_MAX_WC_CELLS) return BSK_ERR_UNSUPPORTED;
+    const size_t out_sz = (4 * sizeof(T) + 15) / 16 * 16;          // BinOut<T, ND <= 4>
+    long long chunk_max = (long long)((s->lds_max - bins_b - tabs_b - 256) / (sizeof(BinRec<T, 3>) + 2)) / 1024 * 1024;
+    chunk_max = std::min<long long>(chunk_max, (long long)(s->lds_max / out_sz) / 1024 * 1024);
+    chunk_max = std::min<long long>(chunk_max, 1024 * WC_PPT);
+    static const int env_wc = getenv("BSK_WC_CHUNK") ? atoi(getenv("BSK_WC_CHUNK")) : 0;                  // measurement knobs
+    static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;
+    static const int env_tot = getenv("BSK_TOT_GRID") ? atoi(getenv("BSK_TOT_GRID")) : 0;
+    if (env_wc > 0) chunk_max = std::min<long long>(chunk_max, std::max(1024, env_wc / 1024 * 1024));
+    if (chunk_max < 2048) return BSK_ERR_UNSUPPORTED;
+    const size_t lds_tot = ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15) + 4 * (size_t)bp.cells;
+    if (lds_tot > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
+
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_lpos = 0, o_rec = o_lpos + up(2 * (size_t)piece), o_tmp = o_rec + up(sizeof(BinRec<T, 3>) * (size_t)piece);
+    const size_t o_tot = o_tmp + up(out_sz * (size_t)piece), o_start = o_tot + up(4 * (size_t)(bp.cells + 1));
+    const size_t o_fill = o_start + up(4 * (size_t)bp.cells), total = o_fill + up(4 * (size_t)bp.cells);
+    HIPCHK(s->bin_ws.reserve(total));
+    char *ws = static_cast<char *>(s->bin_ws.p);
+    unsigned short *lpos = reinterpret_cast<unsigned short *>(ws + o_lpos);
+    BinRec<T, 3> *rec = reinterpret_cast<BinRec<T, 3> *>(ws + o_rec);
+    unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot), *done = tot + bp.cells;
+    unsigned *start = reinterpret_cast<unsigned *>(ws + o_start), *fill = reinterpret_cast<unsigned *>(ws + o_fill);
+    const T *tab = static_cast<const T *>(s->tab);
+    const T *aos = static_cast<const T *>(s->coef_aos);
+    const bool reuse = s->bin_reuse && pieces == 1;               // later derivative passes of a jacobian find the batch sorted
+    bool deriv = false;
+    for (int iv = 0; iv < 3; ++iv) deriv |= w.w[iv] != 0;
+    constexpr bool MF = sizeof(T) == 4;
+    const bool mfma = MF && s->variant != 12;
+    s->last_kernel = mfma ? "cell-order pipeline (eval_cellsort, MFMA)" : "cell-order pipeline (eval_cellsort, VALU)";
+
+    for (long long off = 0; off < n; off += piece) {
+        const long long np = std::min(piece, n - off);
+        Params<T> pp = prm;
+        for (int iv = 0; iv < 3; ++iv) pp.p[iv] = prm.p[iv] + off;
+        bp.chunks = (int)((np + chunk_max - 1) / chunk_max);
+        bp.chunk = (np + bp.chunks - 1) / bp.chunks;
+        bp.ranges = bp.rlen = 1;
+        const int pgrid = std::min(bp.chunks, s->num_cu);
+        stage_mark(s, st, "start", true);
+        if (!reuse) {
+            HIPCHK(hipMemsetAsync(tot, 0, 4 * (size_t)(bp.cells + 1), st));
+            const long long vecs = (np + 16 / (long long)sizeof(T) - 1) / (16 / (long long)sizeof(T));
+            const int tgrid = (int)std::max<long long>(1, std::min<long long>((vecs + 2047) / 2048, (long long)s->num_cu * (env_tot > 0 ? env_tot : 2)));
+            HIPCHK(allow_lds(bin_totals<T>, lds_tot));
+            hipLaunchKernelGGL((bin_totals<T>), dim3(tgrid), dim3(1024), lds_tot, st, d, td, bp, tab, s->lut, pp, np, tot, start, fill, done);
+            stage_mark(s, st, "bin_totals");
+            const size_t lds_s = bins_b + (((size_t)bp.chunk * (sizeof(BinRec<T, 3>) + 2) + 15) & ~(size_t)15) + tabs_b;
+            HIPCHK(allow_lds(bin_scatter_tag<T>, lds_s));
+            hipLaunchKernelGGL((bin_scatter_tag<T>), dim3(pgrid), dim3(1024), lds_s, st, bp, pp, np, off, fill, rec, lpos, d, td, tab, s->lut,
+                               dest_bits, s->bad);
+            stage_mark(s, st, "bin_scatter_tag");
+        }
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((np + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : 4)));
+#define CS_ND(ND)                                                                                                        \
+    case ND: {                                                                                                           \
+        BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
+        if (mfma) {                                                                                                      \
+            if (deriv) {                                                                                                 \
+                HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true>, cs_lds_mfma));                                       \
+                hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d, \
+                                   bp, tab, aos, start, rec, np, tmp, w, dest_bits);                                     \
+            } else {                /* plain evaluation: the recursion without its derivative branches */              \
+                HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, !MF>, cs_lds_mfma));                                        \
+                hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, !MF>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,  \
+                                   bp, tab, aos, start, rec, np, tmp, w, dest_bits);                                     \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            HIPCHK(allow_lds(eval_cellsort<T, O, ND, false>, cs_lds_valu));                                              \
+            hipLaunchKernelGGL((eval_cellsort<T, O, ND, false>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_valu, st, d, bp,    \
+                               tab, aos, start, rec, np, tmp, w, dest_bits);                                             \
+        }                                                                                                                \
+        stage_mark(s, st, "eval_cellsort");                                                                              \
+        const size_t lds_u = (size_t)bp.chunk * sizeof(BinOut<T, ND>);                                                   \
+        HIPCHK(allow_lds(bin_unpermute_stream<T, ND>, lds_u));                                                           \
+        hipLaunchKernelGGL((bin_unpermute_stream<T, ND>), dim3(pgrid), dim3(1024), lds_u, st, bp, np, lpos, tmp, out + off, ostride); \
+        stage_mark(s, st, "bin_unpermute_stream");                                                                       \
+    } break;
+        switch (s->nDep) {
+            CS_ND(1) CS_ND(2) CS_ND(3) CS_ND(4)
+            default: return BSK_ERR_UNSUPPORTED;
+        }
+#undef CS_ND
+        HIPCHK(hipGetLastError());
+    }
+    return BSK_OK;
+}
+
 template <typename T, int NIND, int O, bool MIXED>
 static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
                                      const Wrt &w, hipStream_t st)
@@ -130,8 +237,13 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
             cs_lds_mfma = tab_b + up16(sizeof(T) * (size_t)O * O * 4 * s->ncoef[2]) + rec_b;
             cs_lds_valu = tab_b + up16(sizeof(T) * (size_t)O * O * s->nDep * s->ncoef[2]) + rec_b;
-            cellsort = bp.sh0 == 0 && bp.sh1 == 0 && S2 <= CS_MAX_S2 && s->variant != 13 &&
+            cellsort = bp.sh0 == 0 && bp.sh1 == 0 && S2 <= CS_MAX_S2 && s->variant != 13 && s->variant != 14 &&
                        std::max(cs_lds_mfma, cs_lds_valu) <= s->lds_max / 2;
+            if (cellsort) {
+                const bsk_status r = launch_cellsort_pipeline<T, O>(s, bp, prm, n, out, ostride, w, st, cs_lds_mfma, cs_lds_valu);
+                if (r != BSK_ERR_UNSUPPORTED) return r;
+                cellsort = false;                                 // falls back to the round-2 sort + eval_binned_lds
+            }
         }
 #define BINNED_ND(ND)                                                                                                    \
     case ND: {                                                                                                           \
@@ -156,47 +268,17 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         hipLaunchKernelGGL(bin_scan_top, dim3(1), dim3(1024), 0, st, bp, Tr, start);                                     \
         if (wc) {                                                                                                        \
             size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
-            int keyed = cellsort ? 1 : 0;                                                                                \
-            if (keyed && NIND == 3) {    /* span tables of the third variable behind the chunk when LDS has the room */  \
-                const size_t kb = ((lds_s + 15) & ~(size_t)15) + sizeof(T) * (size_t)((d.nk[2] + 3) & ~3) + 4 * (size_t)td.lut_m[2]; \
-                if (kb + 256 <= s->lds_max) { lds_s = kb; keyed = 2; }                                                   \
-            }                                                                                                            \
+            const int keyed = 0;         /* (round 2 keyed the records for eval_cellsort here; bin_scatter_tag does now) */ \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
                                Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, keyed, s->bad);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, cellsort ? 1 : 0, s->bad);             \
+                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, 0, s->bad);             \
         }                                                                                                                \
-        bool cs_done = false;                                                                                            \
-        if constexpr (NIND == 3 && !MIXED) if (cellsort) {                                                               \
-            cs_done = true;                                                                                              \
-            constexpr bool MF = sizeof(T) == 4;                                                                          \
-            if (MF && s->variant != 12) {                                                                                \
-                s->last_kernel = "cell-order pipeline (eval_cellsort, MFMA)";                                            \
-                bool deriv = false;                                                                                      \
-                for (int iv = 0; iv < 3; ++iv) deriv |= w.w[iv] != 0;                                                    \
-                if (deriv) {                                                                                             \
-                    HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true>, cs_lds_mfma));                                   \
-                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,  \
-                                       bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
-                } else {            /* plain evaluation: the recursion without its derivative branches */              \
-                    HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, !MF>, cs_lds_mfma));                                    \
-                    hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, !MF>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,   \
-                                       bp, tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);           \
-                }                                                                                                        \
-            } else {                                                                                                     \
-                s->last_kernel = "cell-order pipeline (eval_cellsort, VALU)";                                            \
-                HIPCHK(allow_lds(eval_cellsort<T, O, ND, false>, cs_lds_valu));                                          \
-                hipLaunchKernelGGL((eval_cellsort<T, O, ND, false>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_valu, st, d, bp, \
-                                   tab, aos, start, reinterpret_cast<BinRec<T, 3> *>(rec), n, tmp, w);                   \
-            }                                                                                                            \
-        }                                                                                                                \
-        if (!cs_done) {                                                                                                  \
         HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, MIXED>, tab_b + bundle_b));                                     \
         hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, MIXED>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d,    \
                            bp, tab, aos, start, rec, n, tmp, w);                                                         \
-        }                                                                                                                \
         if (wc) {                                                                                                        \
             const size_t lds_u = ((8 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * sizeof(BinOut<T, ND>); \
             HIPCHK(allow_lds(bin_unpermute_wc<T, ND>, lds_u));                                                           \

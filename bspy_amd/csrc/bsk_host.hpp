@@ -96,7 +96,25 @@ struct bsk_spline_s {
     UniDescN<float> un32;
     UniDescN<double> un64;
     const char *last_kernel = "";       // family of the most recent point-kernel launch (bsk_last_kernel)
+    // measurement hook (bsk_debug_stage_times): events between the kernels of the cell-order pipeline
+    static constexpr int MAX_STAGES = 12;
+    bool stage_timing = false;
+    hipEvent_t stage_ev[MAX_STAGES] = {};
+    const char *stage_name[MAX_STAGES] = {};
+    int stage_count = 0;
 };
+
+// bsk_debug_stage_times: an event behind every kernel of a multi-kernel pipeline (only while the hook is enabled)
+inline void stage_mark(bsk_spline s, hipStream_t st, const char *name, bool first = false)
+{
+    if (!s->stage_timing) return;
+    if (first) s->stage_count = 0;
+    if (s->stage_count >= bsk_spline_s::MAX_STAGES) return;
+    hipEvent_t &e = s->stage_ev[s->stage_count];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDefault) != hipSuccess) { e = nullptr; return; }
+    if (hipEventRecord(e, st) != hipSuccess) return;
+    s->stage_name[s->stage_count++] = name;
+}
 
 template <typename T>
 Desc<T> &desc_of(bsk_spline s);

@@ -89,7 +89,9 @@ class ShardedEvaluator:
         Returns (rows, N) if gather else this rank's (rows, n_local); rows = nDep
         (evaluate/derivative) or nDep * nInd (jacobian, row = d * nInd + j).
         ``check=False`` skips the blocking agreement on the first out-of-domain point (a MIN
-        all-reduce + host read per call); a local offender still raises on its own rank."""
+        all-reduce + host read per call).  A rank whose own shard holds an offender still raises,
+        but only AFTER it has taken part in the all-gather (with NaN rows for its shard), so the
+        other ranks are never left waiting in the collective; they receive those NaN rows."""
         import torch
         nind = self.spline.nInd
         if len(points) != nind:
@@ -127,14 +129,27 @@ class ShardedEvaluator:
             bad = torch.tensor([bad_here], dtype=torch.int64, device=cdev)
             self.dist.all_reduce(bad, op=self.dist.ReduceOp.MIN, group=self.group)
             bad_here = int(bad.item())
-        if bad_here != import_max:
+        def raise_bad():
             where = ""
             if not sharded_input:
                 pt = [float(p[bad_here]) for p in points]
                 where = f" {np.atleast_1d(pt)}"
             raise ValueError(f"Spline evaluation outside domain:{where} (flat index {bad_here})")
+        # Without the agreement (check=False) only this rank knows about its offender: it must not
+        # leave the others alone in the all-gather below, so it raises after the collective.
+        deferred = bad_here != import_max and self.coll and gather and not check
+        if bad_here != import_max and not deferred:
+            raise_bad()
         if not gather or not self.coll:
             return res
+        if deferred and res is None:
+            rows = self.spline.nDep * (nind if op == "jacobian" else 1)
+            dt = np.result_type(self.spline.coefs.dtype, *[k.dtype for k in self.spline.knots])
+            if hasattr(local[0], "is_cuda"):
+                is_t = True
+                res = torch.full((rows, stop - start), float("nan"), dtype=getattr(torch, np.dtype(dt).name), device=local[0].device)
+            else:
+                res = np.full((rows, stop - start), np.nan, dtype=dt)
 
         # all-gather: ONE collective into (world, rows, chunk), then one device copy into the (rows, N) layout
         chunk = shard_chunk(n, self.world)
@@ -149,6 +164,8 @@ class ShardedEvaluator:
         gathered = torch.empty((self.world * rows, chunk), dtype=t.dtype, device=t.device)   # rank-major concatenation
         self.dist.all_gather_into_tensor(gathered, t.contiguous(), group=self.group)
         full = gathered.view(self.world, rows, chunk).permute(1, 0, 2).reshape(rows, self.world * chunk)[:, :n]
+        if deferred:
+            raise_bad()
         if is_t:
             return full
         return full.cpu().numpy() if full.device.type != "cpu" else full.numpy()

@@ -214,14 +214,27 @@ bsk_status bsk_multi_jacobian(bsk_multi m, const void *const *uvw, int64_t n, bs
  *   bsk_last_kernel : family name of the kernel the most recent point call on this handle launched
  *                     ("eval_uni", "eval_rowrot", "eval_stream", "cell-order pipeline (...)", ...), so
  *                     that measurements and tests name the kernel that actually ran.
- *   bsk_debug_probe : memory-side floor of the LDS-resident kernels' launch geometry: streams two fp64
- *                     parameter arrays in and three result arrays out with trivial arithmetic
- *                     (mode 0: 8 B per lane per access, mode 1: 16 B), `blocks_per_cu` workgroups of
- *                     `threads` lanes per CU with `lds_bytes` of LDS allocated.  tools/probe_stream.py.
  */
 const char *bsk_last_kernel(bsk_spline s);
+
+/*
+ * BSK_INTERNAL: measurement hooks of this repository's bench.py / tools/.  They are exported by the library but are
+ * NOT part of the product ABI (no reference counterpart, no stability promise): a binding of the reference never
+ * needs them, and they are only declared when the including file asks for them.
+ *   bsk_debug_probe       : memory-side floor of the LDS-resident kernels' launch geometry: streams two fp64
+ *                           parameter arrays in and three result arrays out with trivial arithmetic
+ *                           (mode 0: 8 B per lane per access, mode 1: 16 B), `blocks_per_cu` workgroups of
+ *                           `threads` lanes per CU with `lds_bytes` of LDS allocated.  tools/probe_stream.py.
+ *   bsk_debug_stage_times : per-kernel durations of the cell-order pipeline (HIP events between its kernels on the
+ *                           call's stream).  enable != 0 records the FOLLOWING calls on this handle; a call with
+ *                           ms / names / count returns the stages of the last recorded call (names are static
+ *                           strings, at most `cap` entries).
+ */
+#ifdef BSK_INTERNAL
 bsk_status bsk_debug_probe(bsk_spline s, int mode, int blocks_per_cu, int threads, int64_t lds_bytes,
                            const void *u, const void *v, int64_t n, void *out, void *stream);
+bsk_status bsk_debug_stage_times(bsk_spline s, int enable, float *ms, const char **names, int cap, int *count);
+#endif
 
 #ifdef __cplusplus
 }

@@ -63,9 +63,54 @@ static void work(int seed)
     CHECK(bsk_spline_destroy(s));
 }
 
+// The REAL single-device host code under the multi-device entry points, on every fake device (HIPSTUB_DEVICES):
+// tables replicated per device, BSK_HOST shards on a thread per device, device buffers with the grouped all-gather
+// of the stub librccl.  Kernels are no-ops here (results stay zero); the sanitizer checks every copy's bounds.
+static void multi_work()
+{
+    int ndev = 0;
+    CHECK(bsk_device_count(&ndev));
+    const int order[2] = {4, 4}, ncoef[2] = {16, 12};
+    std::vector<double> ku(order[0] + ncoef[0]), kv(order[1] + ncoef[1]), coefs(3 * ncoef[0] * ncoef[1], 1.0);
+    for (size_t i = 0; i < ku.size(); ++i) ku[i] = i < 4 ? 0.0 : (i >= 16 ? 1.0 : (i - 3) / 13.0);
+    for (size_t i = 0; i < kv.size(); ++i) kv[i] = i < 4 ? 0.0 : (i >= 12 ? 1.0 : (i - 3) / 9.0);
+    const void *knots[2] = {ku.data(), kv.data()};
+    bsk_multi m = nullptr;
+    CHECK(bsk_multi_create(BSK_F64, ndev, nullptr, 2, 3, order, ncoef, knots, coefs.data(), &m));
+    for (long long n : {0LL, 7LL, 100003LL}) {
+        std::vector<double> u(n, 0.25), v(n, 0.5), out((size_t)6 * n);
+        const void *uv[2] = {u.data(), v.data()};
+        void *outs[1] = {out.data()};
+        int64_t bad = 0;
+        const int wrt[2] = {0, 1};
+        CHECK(bsk_multi_evaluate(m, wrt, uv, n, BSK_HOST, outs, 0, &bad));
+        CHECK(bsk_multi_jacobian(m, uv, n, BSK_HOST, outs, 0, &bad));
+        std::vector<int64_t> start(ndev + 1);
+        CHECK(bsk_multi_shard_plan(m, n, start.data()));
+        const long long chunk = n > 0 ? (n + ndev - 1) / ndev : 0;
+        std::vector<std::vector<double>> du(ndev), dv(ndev), dout(ndev);
+        std::vector<const void *> duv(2 * ndev);
+        std::vector<void *> douts(ndev);
+        for (int d = 0; d < ndev; ++d) {
+            du[d].assign(start[d + 1] - start[d] + 1, 0.25);
+            dv[d].assign(start[d + 1] - start[d] + 1, 0.5);
+            dout[d].assign((size_t)6 * ndev * chunk + 1, 0.0);
+            duv[2 * d] = du[d].data();
+            duv[2 * d + 1] = dv[d].data();
+            douts[d] = dout[d].data();
+        }
+        for (int gather = 0; gather < 2; ++gather) {
+            CHECK(bsk_multi_evaluate(m, nullptr, duv.data(), n, BSK_DEVICE, douts.data(), gather, &bad));
+            CHECK(bsk_multi_jacobian(m, duv.data(), n, BSK_DEVICE, douts.data(), gather, &bad));
+        }
+    }
+    CHECK(bsk_multi_destroy(m));
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1) g_big = atoll(argv[1]);
+    multi_work();
     std::thread a(work, 1), b(work, 2);
     a.join();
     b.join();

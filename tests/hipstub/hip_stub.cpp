@@ -1,7 +1,8 @@
 // Minimal host-memory stand-in for the HIP runtime entry points that the HOST half of libbspy_amd.so calls
 // (table upload, workspaces, pinned staging, copy-thread pipeline, streams/events).  TEST INFRASTRUCTURE: it
 // lets tests/test_host_logic.py run bsk_api.hip's host code under AddressSanitizer and ThreadSanitizer on the
-// CPU box (GPU sanitizer runs are not available on the GPU pool).  "Device" memory is host memory, copies are
+// CPU box (GPU sanitizer runs are not available on the GPU pool).  HIPSTUB_DEVICES sets the number of fake devices
+// (the multi-device entry points, bsk_multi.hip, run on 2 - 8 of them).  "Device" memory is host memory, copies are
 // memcpy, streams execute immediately, kernel launches are no-ops (results are whatever calloc left: zeros).
 #include <hip/hip_runtime.h>
 
@@ -15,9 +16,24 @@ static std::atomic<long> g_live{0}, g_launches{0};
 long hipstub_live_allocations() { return g_live.load(); }
 long hipstub_kernel_launches() { return g_launches.load(); }
 
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// HIPSTUB_DEVICES fake devices (default 1): the current device is per thread, as in the HIP runtime
+static int stub_devices()
+{
+    static const int n = [] { const char *e = getenv("HIPSTUB_DEVICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 64 ? v : 1; }();
+    return n;
+}
+static thread_local int t_device = 0;
+static std::atomic<long> g_set_device{0};
+long hipstub_set_device_calls() { return g_set_device.load(); }
+hipError_t hipGetDeviceCount(int *n) { *n = stub_devices(); return hipSuccess; }
+hipError_t hipSetDevice(int d)
+{
+    if (d < 0 || d >= stub_devices()) return hipErrorInvalidDevice;
+    t_device = d;
+    ++g_set_device;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t *p, int)
 {
     memset(p, 0, sizeof(*p));

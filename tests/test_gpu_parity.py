@@ -360,6 +360,57 @@ def test_full_size_properties():
     assert np.abs(jac[:, 1] - d1).max() <= 1e-11 * _scale(d1)
 
 
+@pytest.mark.parametrize("n", [50_000_000, 6_250_000])
+def test_cfg5_full_size_properties(n):
+    """BASELINE configs[4] at its real size: 50 M points on the trivariate order-5 40^3 x 4 fp32 spline (two pieces of
+    the cell-order pipeline: a record's tag holds 26 bits of destination), and the 6.25 M-point shard one of 8 GPUs
+    gets.  Device-resident I/O.  Oracle on a 200 k sample spread over the batch (the end of it included), bitwise
+    determinism, bitwise permutation equivariance, partition of unity, and the first offender near the END of the batch
+    (32-bit slot / chunk arithmetic)."""
+    torch = pytest.importorskip("torch")
+    nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    g = torch.Generator(device="cuda").manual_seed(n % 1000)
+    p = [torch.rand(n, dtype=torch.float32, device="cuda", generator=g) for _ in range(3)]
+    p[0][-3:] = 1.0                                              # the domain's right end, at the very end of the batch
+    p[2][-1] = 0.0
+    out = t.evaluate_device(p)
+    assert "eval_cellsort" in t.last_kernel()
+    rng = np.random.default_rng(3)
+    idx = np.unique(np.concatenate([rng.integers(0, n, 200_000), np.arange(n - 4096, n), np.arange(4096)]))
+    tidx = torch.as_tensor(idx, device="cuda")
+    host = [x[tidx].cpu().numpy() for x in p]
+    orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0, 0], host)
+    assert bad == -1
+    err = float(np.abs(out[:, tidx].cpu().numpy() - orc).max() / _scale(orc))
+    print(f"cfg5 {n} points: worst error on {len(idx)} sampled points {err:.2e} of the scale")
+    assert err <= 2e-5
+    assert torch.equal(out, t.evaluate_device(p))                # determinism (the SLOT of a record is not deterministic, its result is)
+    perm = torch.randperm(n, device="cuda", generator=g)
+    outp = t.evaluate_device([x[perm] for x in p])
+    assert torch.equal(outp, out[:, perm])                       # no dependence on a point's position in the batch
+    del outp, perm
+    d1 = t.evaluate_device(p, [0, 1, 0])                         # a derivative pass at full size, on the same sample
+    od, _ = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 1, 0], host)
+    assert float(np.abs(d1[:, tidx].cpu().numpy() - od).max() / _scale(od)) <= 2e-5
+    del d1
+    ones = DeviceSpline(order, ncoef, knots, np.ones_like(coefs), dt)
+    one = ones.evaluate_device(p)
+    assert float((one - 1.0).abs().max()) <= 1e-5                # partition of unity
+    del one
+    p[1][n - 7] = 1.5                                            # first offender near the end; a later one behind it
+    p[0][n - 2] = -0.25
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate_device(p)
+    assert e.value.index == n - 7
+    p[1][n - 7] = 0.5
+    p[0][n - 2] = 0.5
+    p[2][n // 2 + 11] = 1.0 + 1e-6                               # the third variable (tested by the scatter kernel), second piece
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate_device(p)
+    assert e.value.index == n // 2 + 11
+
+
 def test_empty_and_ragged():
     c = CASES["cfg2_bicubic"]
     t = _tables(c)
@@ -560,11 +611,12 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
 
 
 @pytest.mark.parametrize("variant,kernel", [("0", "eval_cellsort, MFMA"), ("12", "eval_cellsort, VALU"), ("13", "eval_binned_lds"),
-                                            ("14", "eval_cellsort, MFMA"), ("7", "eval_gather")])
+                                            ("14", "eval_binned_lds"), ("7", "eval_gather")])
 def test_cell_order_pipeline_variants(variant, kernel, monkeypatch):
     """Every form of the large-table path on the cfg5 shape (three variables, order 5, 40^3 x 4, fp32) against the
-    oracle: MFMA and VALU contraction of eval_cellsort, round 1's eval_binned_lds, the direct (14) instead of the
-    write-combining scatter / un-permute, and the gather kernel in batch order (7)."""
+    oracle: MFMA and VALU contraction of eval_cellsort (round-3 sort: bin_totals / bin_scatter_tag / bin_unpermute_stream),
+    round 1's eval_binned_lds behind the round-2 sort (chunk histograms + scans; 13), the same with the direct instead of
+    the write-combining scatter / un-permute (14), and the gather kernel in batch order (7)."""
     monkeypatch.setenv("BSK_VARIANT", variant)
     nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
     t = DeviceSpline(order, ncoef, knots, coefs, dt)
@@ -1345,6 +1397,28 @@ def test_uniform_path_declines_knots_far_from_the_origin():
     near = DeviceSpline((order, order), ncoef, [_uniform_knots(order, nc, 10.0, 10.5) for nc in ncoef], coefs)
     near.evaluate([rng.uniform(10.0, 10.5, 100), rng.uniform(10.0, 10.5, 100)])
     assert near.last_kernel() == "eval_uni"
+
+
+def test_uniform_path_declines_perturbed_knots():
+    """Knots moved by a few hundred ulp of the span are the user's data, not rounding: the table-free kernels (which
+    form every alpha from the nominal span width) must decline them, and the general kernels meet the parity bar."""
+    rng = np.random.default_rng(6)
+    order, ncoef = 4, (64, 64)
+    knots = [_uniform_knots(order, nc, 0.0, 1.0) for nc in ncoef]
+    h = 1.0 / (ncoef[0] - order + 1)
+    for k in knots:
+        k[order:ncoef[0]] += rng.uniform(-500, 500, ncoef[0] - order) * np.finfo(np.float64).eps * h
+    coefs = rng.standard_normal((3, *ncoef))
+    t = DeviceSpline((order, order), ncoef, knots, coefs)
+    pts = [rng.random(20000), rng.random(20000)]
+    worst = 0.0
+    for w in ([0, 0], [1, 2]):
+        out = t.evaluate(pts, w)
+        assert t.last_kernel() == "eval_rowrot"
+        orc, bad = oracle.c_evaluate((order, order), ncoef, knots, coefs, w, pts)
+        worst = max(worst, float(np.abs(out - orc).max() / _scale(orc)))
+    print(f"perturbed knots on the general kernels: worst error {worst:.2e} of the scale")
+    assert worst <= 1e-13
 
 
 @pytest.mark.parametrize("order,ncoef,dom,clamps,nDep,dt,expect", [

@@ -25,8 +25,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "bspy_amd.h")).read()
+    internal_block = header[header.index("#ifdef BSK_INTERNAL"):]
+    internal_block = internal_block[:internal_block.index("#endif")]
+    internal = set(re.findall(r"\b(bsk_[a-z_]+)\s*\(", internal_block))
     declared = set(re.findall(r"\b(bsk_[a-z_]+)\s*\(", header))
     declared -= {"bsk_status"}
+    assert internal == set(_native.INTERNAL_SYMBOLS)                      # measurement hooks: behind BSK_INTERNAL only
+    assert declared - internal == set(_native.PRODUCT_SYMBOLS)
     assert declared == set(_native.SYMBOLS)
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
@@ -188,6 +193,21 @@ try:
     raise SystemExit("no error raised")
 except ValueError as e:
     assert "outside domain" in str(e) and "flat index 900" in str(e), str(e)   # every rank reports the first offender
+# check=False: no agreement step.  The offending rank (the last one: index 900) must still take part in the
+# all-gather - it raises afterwards - and the other rank returns with NaN rows for that shard (no hang).
+owner = [r for r in range(world) if shard_bounds(n, world, r)[0] <= 900 < shard_bounds(n, world, r)[1]][0]
+try:
+    got = sh.evaluate(bad, check=False)
+    assert rank != owner, "the offending rank must raise"
+    oa, ob = shard_bounds(n, world, owner)
+    assert np.isnan(got[:, oa:ob]).all() and np.array_equal(got[:, :oa], full[:, :oa]), "NaN rows of the offending shard"
+except ValueError as e:
+    assert rank == owner and "flat index 900" in str(e), str(e)
+try:
+    loc = sh.jacobian(bad, gather=False, check=False)        # no collective at all: the offender raises at once
+    assert rank != owner
+except ValueError as e:
+    assert rank == owner
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -433,7 +453,33 @@ def test_host_code_under_address_and_thread_sanitizer(tmp_path):
         out, _ = p.communicate(timeout=900)
         assert p.returncode == 0, f"{k} build failed:\n{out[-3000:]}"
     for k, big in (("asan", "4500000"), ("tsan", "2200000")):
-        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", TSAN_OPTIONS="halt_on_error=1")
+        # three fake devices: the multi-device entry points run the REAL single-device host code on each of them
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", TSAN_OPTIONS="halt_on_error=1",
+                   HIPSTUB_DEVICES="3", LD_LIBRARY_PATH=str(tmp_path / k) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
         r = subprocess.run([str(tmp_path / k / "driver"), big], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0 and "hipstub driver ok" in r.stdout, f"{k}:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
+        assert "Sanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+def test_multi_device_entry_points_on_fake_devices(tmp_path):
+    """bsk_multi_evaluate / bsk_multi_jacobian (csrc/bsk_multi.hip, compiled host-only and unchanged) on 1, 2, 3 and 8
+    fake devices with a stub librccl (tests/hipstub/rccl_stub.cpp: grouped all-gather as memcpy) and a recognisable
+    stand-in for the single-device layer (tests/hipstub/multi_driver.cpp): every value of every shard, staging block
+    and gathered buffer is checked - ragged tail, empty tail shards, n = 0, first offender on the last device, a
+    failing device in the middle (all devices drained, current device restored) - under ASAN and TSAN."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    stub = os.path.join(ROOT, "tests", "hipstub")
+    procs = {k: subprocess.Popen(["bash", os.path.join(stub, "build_multi.sh"), k, str(tmp_path / k)], stdout=subprocess.PIPE,
+                                 stderr=subprocess.STDOUT, text=True) for k in ("asan", "tsan")}
+    for k, p in procs.items():
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, f"{k} build failed:\n{out[-3000:]}"
+    for k in ("asan", "tsan"):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", TSAN_OPTIONS="halt_on_error=1",
+                   HIPSTUB_DEVICES="8", LD_LIBRARY_PATH=str(tmp_path / k) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([str(tmp_path / k / "multi_driver")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "multi driver ok: 8 devices, 48 cases" in r.stdout, f"{k}:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
         assert "Sanitizer" not in r.stderr, r.stderr[-6000:]
