@@ -16,6 +16,13 @@ carry "weak" (10 M points per rank) and "with_allgather" (the RCCL all-gather of
 Prints ONE JSON line (rank 0).  roofline.achieved uses the ALGORITHMIC bytes of SURVEY.md 8(d):
 40 B per eval (2 x 8 B in + 3 x 8 B out) against 8 TB/s HBM3E, over the average launch duration
 measured with HIP events on the launch stream inside the timed region.
+
+`--config {2,3,4,5}` selects the BASELINE config the job runs (default 2 = the metric's; the others are the
+parity-test configs, runnable sharded so that an 8-GPU node can drive each of them):
+    3  same bicubic: derivative([1,1]) + fused jacobian per step (104 B per point), all-gather of (3,N) and (3,2,N)
+    4  Utah teapot, 32 bicubic fp32 patches on a 2048 x 2048 grid each, sharded BY PATCH (12 B per grid point)
+    5  trivariate order 5, 40^3 x 4, fp32, 50 M points (28 B per point): the cell-order pipeline, with its per-kernel
+       times (sort_ms / eval_ms), and the fp32-ALU / MFMA fractions next to the HBM one
 """
 import argparse
 import ctypes
@@ -34,6 +41,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 N_POINTS = 10_000_000
 BYTES_PER_EVAL = {"evaluate": 40, "derivative": 40, "jacobian": 64, "normal": 40}
+FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak = fp32 MFMA peak (MI355X_MICROARCH.md)
+CFG5_FLOP_PER_POINT = 1450     # algorithmic fp32 flop per cfg5 point
+CFG5_MFMA_FLOP_PER_POINT = 1000  # the part of them the 4x4x1 MFMAs carry: 125 control points x 4 dependents x 2
 PROFILE_DIR = "profiles/r02_eval_uni"    # rocprofv3 summaries of this command (kernel trace + PMC passes)
 
 
@@ -205,13 +215,206 @@ def host_end_to_end(tables, uv, n):
             "note": "Spline.evaluate on NumPy arrays: H2D + kernel + D2H over PCIe, never `value`"}
 
 
+def run_other_config(args, torch, dist, dev, world, rank):
+    """BASELINE configs[2], [3], [4] (--config 3 / 4 / 5) with the same protocol as the headline: device-resident
+    synthetic inputs, W warm-up steps, K timed steps between barrier + synchronize, MAX over ranks, one JSON line.
+    Strong scaling: the config's whole job is sharded over the ranks (points contiguously, cfg4 by patch), no
+    collective in the timed region; `with_allgather` (N > 1) adds the RCCL all-gather of the results."""
+    import cases
+    import bspy_amd
+    from bspy_amd import _native as nv
+    from bspy_amd.sharding import shard_bounds
+    lib = nv.lib()
+    stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    cfg = args.config
+    info = {}
+
+    if cfg in (3, 5):
+        nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(cfg)
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        n_total = args.points if args.points != N_POINTS or cfg == 3 else 50_000_000
+        start, stop = shard_bounds(n_total, world, rank)
+        n_local = stop - start
+        tables = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt, device=dev.index)
+        g = torch.Generator(device=dev).manual_seed(1000 + rank)
+        pts = [torch.rand(max(n_local, 1), dtype=tdt, device=dev, generator=g)[:n_local] for _ in range(nind)]
+        ptrs = nv.ptr_array([p.data_ptr() for p in pts])
+        if cfg == 3:
+            outs = [torch.empty((ndep, n_local), dtype=tdt, device=dev), torch.empty((ndep * nind, n_local), dtype=tdt, device=dev)]
+            wrt_arr = nv.int_array([1, 1])
+            o0, o1 = ctypes.c_void_p(outs[0].data_ptr()), ctypes.c_void_p(outs[1].data_ptr())
+
+            def step():
+                if n_local == 0:
+                    return
+                st = lib.bsk_evaluate(tables._handle, wrt_arr, ptrs, n_local, nv.BSK_DEVICE, o0, stream_ptr, None)
+                if st == 0:
+                    st = lib.bsk_jacobian(tables._handle, ptrs, n_local, nv.BSK_DEVICE, o1, stream_ptr, None)
+                if st != 0:
+                    nv.check(st)
+            bpe = 104
+            workload = ("BASELINE configs[2]: bicubic surface order 4x4, nCoef 64x64, nDep 3, fp64: Spline.derivative([1,1]) + fused "
+                        f"jacobian (two C-ABI calls per step) on {n_total} uniform-random (u,v)")
+            metric = "M evals/sec (derivative + jacobian pairs) on 10M-point bicubic (p=3x3) surface"
+        else:
+            outs = [torch.empty((ndep, n_local), dtype=tdt, device=dev)]
+            o0 = ctypes.c_void_p(outs[0].data_ptr())
+
+            def step():
+                if n_local == 0:
+                    return
+                st = lib.bsk_evaluate(tables._handle, None, ptrs, n_local, nv.BSK_DEVICE, o0, stream_ptr, None)
+                if st != 0:
+                    nv.check(st)
+            bpe = 28
+            workload = ("BASELINE configs[4]: trivariate manifold nInd 3, order 5, nCoef 40^3, nDep 4, fp32, clamped uniform knots, "
+                        f"Spline.evaluate on {n_total} uniform-random (u,v,w)")
+            metric = "M evals/sec on 50M-point trivariate (order 5, 40^3 x 4, fp32) manifold"
+        units_local, units_total = n_local, n_total
+        unit_name = "points"
+        gather_rows = [o.shape[0] for o in outs]
+        gather_chunk = -(-n_total // world)
+
+        def gather_blocks():
+            return [(o, o.shape[0], gather_chunk, n_local) for o in outs]
+        status = tables
+    elif cfg == 4:
+        tbl = np.load(os.path.join(ROOT, "tests", "golden", "reference_tables.npz"))
+        allp = cases.teapot_patches(tbl)
+        start, stop = shard_bounds(len(allp), world, rank)
+        patches = [bspy_amd.DeviceSpline(o, c, k, cf, np.float32, device=dev.index) for (o, c, k, cf) in allp[start:stop]]
+        side = 2048
+        gg = torch.linspace(0, 1, side, dtype=torch.float32, device=dev)
+        npl = len(patches)
+        pos = torch.empty((max(npl, 1), 3, side, side), dtype=torch.float32, device=dev)[:npl]
+        tdt = torch.float32
+
+        def step():
+            if npl:
+                bspy_amd.tessellate_tables(patches, (gg, gg), normals=False, out=(pos, None), check=False)
+        bpe = 12
+        units_local, units_total = npl * side * side, len(allp) * side * side
+        unit_name = "grid points"
+        workload = (f"BASELINE configs[3]: Utah teapot, {len(allp)} bicubic fp32 Bezier patches on a dense {side} x {side} grid each "
+                    "(positions), one bsk_tessellate call per step, sharded by patch")
+        metric = "M evals/sec on the 32-patch teapot 2048x2048 tessellation"
+        per_rank = -(-len(allp) // world)
+
+        def gather_blocks():
+            return [(pos.reshape(npl, 3 * side * side), per_rank, 3 * side * side, None)]
+        status = patches[0] if patches else None
+        tables = patches[0] if patches else None
+    else:
+        raise SystemExit(f"unknown --config {cfg}")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(f):
+        for _ in range(args.warmup):
+            f()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        elapsed, kernel_ms = t1 - t0, e0.elapsed_time(e1) / args.steps
+        if dist is not None:
+            tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms = float(tt[0]), float(tt[1])
+        return elapsed, kernel_ms
+
+    barrier()
+    t_end = time.perf_counter() + 0.15                   # clock spin-up on the measured step itself
+    while time.perf_counter() < t_end:
+        step()
+    torch.cuda.synchronize()
+    elapsed, kernel_ms = measure(step)
+    if status is not None:
+        status.domain_status()
+    kernel = tables.last_kernel() if tables is not None else ""
+
+    extra = {}
+    if cfg == 5 and units_local > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from cfg5_stages import stage_times
+        st_ms = stage_times(tables, step, reps=max(3, min(args.steps, 10)))
+        sort_ms = sum(v for k, v in st_ms.items() if not k.startswith("eval"))
+        eval_ms = sum(v for k, v in st_ms.items() if k.startswith("eval"))
+        sec = kernel_ms * 1e-3
+        extra["pipeline"] = {
+            "stages_ms": {k: round(v, 4) for k, v in st_ms.items()}, "sort_ms": round(sort_ms, 4), "eval_ms": round(eval_ms, 4),
+            "alu_frac": round(CFG5_FLOP_PER_POINT * units_local / sec / 1e12 / FP32_PEAK_TFLOPS, 4),
+            "alu_frac_of_eval_kernel": round(CFG5_FLOP_PER_POINT * units_local / (eval_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if eval_ms else None,
+            "mfma_frac_of_eval_kernel": round(CFG5_MFMA_FLOP_PER_POINT * units_local / (eval_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if eval_ms else None,
+            "note": ("HIP events between the pipeline's kernels (bsk_debug_stage_times); alu_frac = 1450 algorithmic fp32 flop per "
+                     "point against the 157.3 TFLOP/s vector peak (SURVEY 8d: the bound that applies - the table gather is served "
+                     "from LDS); mfma_frac = the 1000 flop per point the v_mfma_f32_4x4x1 instructions carry against the fp32 "
+                     "matrix peak (also 157.3), over the evaluation kernel's own time"),
+        }
+    if dist is not None:
+        blocks = gather_blocks()
+        bufs = []
+        for (t, rows, width, valid) in blocks:
+            send = torch.zeros((rows, width), dtype=tdt, device=dev)
+            full = torch.empty((world * rows, width), dtype=tdt, device=dev)
+            bufs.append((t, send, full, valid))
+
+        def gstep():
+            step()
+            for (t, send, full, valid) in bufs:
+                if valid is None:
+                    send[:t.shape[0]].copy_(t)           # cfg4: whole patches, the tail rank may hold fewer
+                else:
+                    send[:, :valid].copy_(t)             # point shards: the tail rank's may be short
+                dist.all_gather_into_tensor(full, send)
+        gel, _ = measure(gstep)
+        gsec = gel / args.steps
+        nbytes = sum(send.numel() * send.element_size() for (_, send, _, _) in bufs)
+        extra["with_allgather"] = {"value": round(units_total / gsec / 1e6, 1), "unit": "M evals/s", "ms_per_step": round(gsec * 1e3, 4),
+                                   "allgather_bytes_per_rank_in": (world - 1) * nbytes,
+                                   "xgmi_in_GBs_per_gpu": round((world - 1) * nbytes / gsec / 1e9, 1)}
+        del bufs
+
+    if rank == 0:
+        sec_step = elapsed / args.steps
+        achieved = bpe * units_local / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": metric, "value": round(units_total / sec_step / 1e6, 1), "unit": "M evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_step * 1e3, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if tdt == torch.float64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": cfg, f"{unit_name.replace(' ', '_')}_total": units_total,
+                       f"{unit_name.replace(' ', '_')}_per_gpu": units_local,
+                       "sharding": ("patches" if cfg == 4 else "contiguous shards of ceil(N / ranks) points") + ", no collective in the timed region"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_eval": bpe, "algorithmic_bytes_per_launch": bpe * units_local},
+        }
+        res.update(extra)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--op", choices=["evaluate", "derivative", "jacobian", "normal"], default="evaluate")
-    ap.add_argument("--points", type=int, default=N_POINTS, help="points of the whole job (sharded over the ranks)")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2,
+                    help="BASELINE config of the job: 2 = the metric's (default), 3 = derivative + jacobian, 4 = teapot tessellation, 5 = trivariate fp32")
+    ap.add_argument("--points", type=int, default=N_POINTS, help="points of the whole job (sharded over the ranks; config 5 defaults to 50 M)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host end-to-end legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (reported beside the headline, N=1 only)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
@@ -244,9 +447,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    dev = torch.device("cuda", local_rank)
+    if args.config != 2:
+        return run_other_config(args, torch, dist, dev, world, rank)
     nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(2)
     n_total = args.points
-    dev = torch.device("cuda", local_rank)
     lib = nv.lib()
     tables = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt, device=local_rank)
     handle = tables._handle

@@ -298,6 +298,8 @@ extern "C" bsk_status bsk_spline_destroy(bsk_spline s)
     s->aux_ws.release();
     s->curv_ws.release();
     s->bin_ws.release();
+    if (s->ticket) (void)hipFree(s->ticket);
+    s->ticket = nullptr;
     s->uni_img.release();
     if (s->pin) (void)hipHostFree(s->pin);
     s->pin = nullptr;

@@ -572,17 +572,17 @@ __device__ __forceinline__ unsigned block_excl_scan(const unsigned (&v)[PER], un
     return run;
 }
 
+// bin_totals: workgroup w counts the bins of the chunks w, w + G, w + 2 G, ... - exactly the chunks workgroup w of
+// bin_scatter_tag (same grid) will move - and writes ONE histogram row rows[w][cells] (plain coalesced stores: adding
+// the rows into shared totals with atomics measured 150 us per 10 M points - hundreds of workgroups adding to the same
+// 40 lines serialise at the memory side).  16-byte loads; no barrier between chunks.
 // LDS: [knots + bucket tables of variables 0, 1][cells x u32]
 template <typename T>
 __global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDesc<T> td, const BinPlan bp,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
-                                                   const Params<T> prm, const long long N, unsigned *__restrict__ tot,
-                                                   unsigned *__restrict__ start, unsigned *__restrict__ fill,
-                                                   unsigned *__restrict__ done)
+                                                   const Params<T> prm, const long long N, unsigned *__restrict__ rows)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned s_wave[16];
-    __shared__ int s_last;
     const SpanLds<T> sl = span_lds_stage<T, 2>(smem, d, td, gtab, glut);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15));
     const int cells = bp.cells;
@@ -590,49 +590,122 @@ __global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDe
     __syncthreads();
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(V)));
-    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+    // chunks start at multiples of 8 points (host): 16-byte loads whenever the caller's arrays are 16-byte aligned
     const bool aligned = ((reinterpret_cast<size_t>(prm.p[0]) | reinterpret_cast<size_t>(prm.p[1])) & 15) == 0;
-    const long long nvec = aligned ? N / V : 0;                 // 16-byte groups; the rest (and misaligned batches) one by one
-    for (long long g = gtid; g < nvec; g += 2 * gstride) {
-        const long long g1 = g + gstride;
-        const bool two = g1 < nvec;
-        const vecT a0 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[0]) + g);
-        const vecT b0 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[1]) + g);
-        const vecT a1 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[0]) + (two ? g1 : g));
-        const vecT b1 = __builtin_nontemporal_load(reinterpret_cast<const vecT *>(prm.p[1]) + (two ? g1 : g));
+    // a chunk (<= 8192 points) is at most 2 (fp32) / 4 (fp64) vectors per lane and variable: the next chunk's are
+    // requested before this chunk's are counted
+    constexpr int VPL = WC_PPT / V;
+    vecT a[VPL], bq[VPL];
+    auto fetch = [&](int c) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int nvec = aligned ? (int)(hi - lo) / V : 0;
+        const vecT *pu = reinterpret_cast<const vecT *>(prm.p[0] + lo), *pv = reinterpret_cast<const vecT *>(prm.p[1] + lo);
 #pragma unroll
-        for (int k = 0; k < V; ++k) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, a0[k], b0[k])], 1u);
-        if (two) {
-#pragma unroll
-            for (int k = 0; k < V; ++k) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, a1[k], b1[k])], 1u);
+        for (int k = 0; k < VPL; ++k) {
+            const int g = k * 1024 + (int)threadIdx.x;
+            if (g < nvec) { a[k] = __builtin_nontemporal_load(pu + g); bq[k] = __builtin_nontemporal_load(pv + g); }
         }
+    };
+    int c = blockIdx.x;
+    if (c < bp.chunks) fetch(c);
+    for (; c < bp.chunks; c += gridDim.x) {
+        const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
+        const int cnt = (int)(hi - lo);
+        const int nvec = aligned ? cnt / V : 0;
+        vecT ca[VPL], cb[VPL];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) { ca[k] = a[k]; cb[k] = bq[k]; }
+        if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            if (k * 1024 + (int)threadIdx.x < nvec) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, ca[k][q], cb[k][q])], 1u);
+            }
+        }
+        for (int i = nvec * V + (int)threadIdx.x; i < cnt; i += blockDim.x)
+            atomicAdd(&hist[bin_of<T>(sl, d, td, bp, prm.p[0][lo + i], prm.p[1][lo + i])], 1u);
     }
-    for (long long n = nvec * V + gtid; n < N; n += gstride) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, prm.p[0][n], prm.p[1][n])], 1u);
     __syncthreads();
-    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
-        const unsigned h = hist[i];
-        if (h) atomicAdd(&tot[i], h);                           // device-scope adds: complete before this workgroup's ticket
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) rows[(size_t)blockIdx.x * cells + i] = hist[i];
+}
+
+// bin_starts: rows[w][b] -> exclusive prefix over the workgroups INSIDE every bin (in place), bin totals, and - by the
+// last workgroup to finish (ticket) - the exclusive prefix of the totals over the bins: start[b].  The first slot of
+// workgroup w's records of bin b is start[b] + rows[w][b].
+// Workgroup = 64 bins x 16 groups of rows (1024 lanes): a lane scans its group's rows (16 in flight), the 16 groups of
+// a bin are combined through LDS.
+__global__ __launch_bounds__(1024) void bin_starts(const int cells, const int G, unsigned *__restrict__ rows, unsigned *__restrict__ tot,
+                                                    unsigned *__restrict__ start, unsigned *__restrict__ done)
+{
+    __shared__ unsigned part[16][65];
+    __shared__ unsigned s_wave[16];
+    __shared__ int s_last;
+    const int bl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + bl;
+    const int rpg = (G + 15) / 16;                              // rows per group
+    const int r0 = grp * rpg, r1 = r0 + rpg < G ? r0 + rpg : G;
+    // pass 1: the group's sum (its first 16 rows stay in registers: the whole group when G <= 256)
+    unsigned sum = 0, v0[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v0[k] = (b < cells && r0 + k < r1) ? rows[(size_t)(r0 + k) * cells + b] : 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += v0[k];
+    if (b < cells)
+        for (int r = r0 + 16; r < r1; r += 16) {
+            unsigned v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = r + k < r1 ? rows[(size_t)(r + k) * cells + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += v[k];
+        }
+    part[grp][bl] = sum;
+    __syncthreads();
+    unsigned run = 0, total = 0;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) {
+        const unsigned p = part[g2][bl];
+        run += g2 < grp ? p : 0u;
+        total += p;
+    }
+    // pass 2: exclusive prefixes, written once
+    if (b < cells) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (r0 + k < r1) rows[(size_t)(r0 + k) * cells + b] = run;
+            run += v0[k];
+        }
+        for (int r = r0 + 16; r < r1; r += 16) {
+            unsigned v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = r + k < r1 ? rows[(size_t)(r + k) * cells + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (r + k < r1) rows[(size_t)(r + k) * cells + b] = run;
+                run += v[k];
+            }
+        }
+        if (grp == 0) tot[b] = total;
     }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    // the last workgroup: every other workgroup's adds came before its ticket.  The totals are read with atomics too
-    // (an atomic read-and-reset: served where the adds were made, never from a stale line of this XCD's L2).
+    // last workgroup: the totals of the others were written and released (__threadfence) before their tickets
     constexpr int PER = BIN_MAX_CELLS / 1024;
     const int per = (cells + 1023) / 1024;
     unsigned v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int k = (int)threadIdx.x * per + i;
-        v[i] = (i < per && k < cells) ? atomicExch(&tot[k], 0u) : 0u;
+        v[i] = (i < per && k < cells) ? atomicAdd(&tot[k], 0u) : 0u;       // read where device-scope atomics are served, not from this XCD's L2
     }
-    unsigned run = block_excl_scan<PER>(v, s_wave);
+    unsigned first = block_excl_scan<PER>(v, s_wave);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int k = (int)threadIdx.x * per + i;
-        if (i < per && k < cells) { start[k] = run; fill[k] = run; run += v[i]; }
+        if (i < per && k < cells) { start[k] = first; first += v[i]; }
     }
     if (threadIdx.x == 0) atomicExch(done, 0u);
 }
@@ -651,11 +724,17 @@ __device__ __forceinline__ unsigned word_tag(T w)
     return (unsigned)__builtin_bit_cast(Tag, w);
 }
 
-// LDS: [counts -> run starts: cells x u32][local bin starts: cells x u32][records: chunk x 16 / 32 B][bins: chunk x u16]
-//      [knots + bucket tables of the three variables]
+// bin_scatter_tag: same grid as bin_totals.  Workgroup w owns, in every bin b, the slots from start[b] + rows[w][b]
+// on: a private cursor per bin in LDS, bumped chunk by chunk - no global atomics, no per-chunk tables, and the slot
+// of every record is deterministic.
+// LDS: [counts: cells x u32][cursors: cells x u32][local bin starts: cells x u16][records: chunk x 16 / 32 B]
+//      [bins: chunk x u16][knots + bucket tables of the three variables]
+constexpr int TAG_PPT = BIN_MAX_CELLS / 1024;       // bins per lane of the 1024-lane sort kernels
+
 template <typename T>
 __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const Params<T> prm, const long long N, const long long base,
-                                                        unsigned *__restrict__ fill, BinRec<T, 3> *__restrict__ rec,
+                                                        const unsigned *__restrict__ rows, const unsigned *__restrict__ start,
+                                                        BinRec<T, 3> *__restrict__ rec,
                                                         unsigned short *__restrict__ lpos, const Desc<T> d, const TileDesc<T> td,
                                                         const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                         const int dest_bits, unsigned long long *bad)
@@ -663,15 +742,19 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_wave[16];
     const int cells = bp.cells;
-    unsigned *lcnt = reinterpret_cast<unsigned *>(smem);     // counts of the chunk; after the scan: global start of the bin's run
-    unsigned *locb = lcnt + cells;
-    BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + ((8 * (size_t)cells + 15) & ~(size_t)15));
+    unsigned *lcnt = reinterpret_cast<unsigned *>(smem);
+    unsigned *cursor = lcnt + cells;
+    unsigned short *locb = reinterpret_cast<unsigned short *>(cursor + cells);
+    const size_t bins_b = (10 * (size_t)cells + 15) & ~(size_t)15;
+    BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + bins_b);
     unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
-    char *tabs = smem + ((8 * (size_t)cells + 15) & ~(size_t)15) + (((size_t)bp.chunk * (sizeof(BinRec<T, 3>) + 2) + 15) & ~(size_t)15);
+    char *tabs = smem + bins_b + (((size_t)bp.chunk * (sizeof(BinRec<T, 3>) + 2) + 15) & ~(size_t)15);
     const SpanLds<T> sl = span_lds_stage<T, 3>(tabs, d, td, gtab, glut);
-    constexpr int NEXT_PPT = (BIN_MAX_WC_CELLS + 1023) / 1024;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) cursor[i] = start[i] + rows[(size_t)blockIdx.x * cells + i];
     const int per = (cells + 1023) / 1024;
-    T pu[WC_PPT], pv[WC_PPT], pw[WC_PPT];
+    // the NEXT chunk's points are requested at the top of an iteration (second register set): they stream in while
+    // this chunk is counted, ordered and stored
+    T nu[WC_PPT], nv[WC_PPT], nw[WC_PPT];
     auto fetch = [&](int c) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
@@ -679,9 +762,9 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
         for (int k = 0; k < WC_PPT; ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
             const long long nn = lo + (i < cnt ? i : cnt - 1);
-            pu[k] = __builtin_nontemporal_load(&prm.p[0][nn]);
-            pv[k] = __builtin_nontemporal_load(&prm.p[1][nn]);
-            pw[k] = __builtin_nontemporal_load(&prm.p[2][nn]);
+            nu[k] = __builtin_nontemporal_load(&prm.p[0][nn]);
+            nv[k] = __builtin_nontemporal_load(&prm.p[1][nn]);
+            nw[k] = __builtin_nontemporal_load(&prm.p[2][nn]);
         }
     };
     int c = blockIdx.x;
@@ -689,7 +772,11 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
     for (; c < bp.chunks; c += gridDim.x) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
-        __syncthreads();                                          // the previous chunk's store phase is done with LDS (and the tables are staged)
+        T pu[WC_PPT], pv[WC_PPT], pw[WC_PPT];
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) { pu[k] = nu[k]; pv[k] = nv[k]; pw[k] = nw[k]; }
+        if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);
+        __syncthreads();                                          // the previous chunk's store phase is done with LDS (first: tables, cursors staged)
         for (int i = threadIdx.x; i < cells; i += blockDim.x) lcnt[i] = 0u;
         __syncthreads();
         unsigned ck[WC_PPT], rk[WC_PPT], tg[WC_PPT];
@@ -705,31 +792,26 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
             }
         }
         __syncthreads();
-        // exclusive scan of the bin counts -> first local position of every bin; the bin's run in `rec` is claimed with
-        // ONE returned atomic per bin and chunk (contiguous addresses per wave instruction)
-        unsigned v[NEXT_PPT], g[NEXT_PPT];
+        {   // exclusive scan of the bin counts -> first local position of every bin
+            unsigned v[TAG_PPT];
 #pragma unroll
-        for (int i = 0; i < NEXT_PPT; ++i) {
-            const int b = (int)threadIdx.x * per + i;
-            v[i] = i < per && b < cells ? lcnt[b] : 0u;
-        }
-        unsigned run = block_excl_scan<NEXT_PPT>(v, s_wave);
+            for (int i = 0; i < TAG_PPT; ++i) {
+                const int b = (int)threadIdx.x * per + i;
+                v[i] = i < per && b < cells ? lcnt[b] : 0u;
+            }
+            unsigned run = block_excl_scan<TAG_PPT>(v, s_wave);
 #pragma unroll
-        for (int i = 0; i < NEXT_PPT; ++i) {
-            const int b = (int)threadIdx.x * per + i;
-            g[i] = 0u;
-            if (i < per && b < cells) {
-                locb[b] = run;
-                run += v[i];
-                if (v[i]) g[i] = atomicAdd(&fill[b], v[i]);
+            for (int i = 0; i < TAG_PPT; ++i) {
+                const int b = (int)threadIdx.x * per + i;
+                if (i < per && b < cells) { locb[b] = (unsigned short)run; run += v[i]; }
             }
         }
-        __syncthreads();                                          // local bin starts complete; every count has been read
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < WC_PPT; ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
             if (i < cnt) {
-                const unsigned p = locb[ck[k]] + rk[k];
+                const unsigned p = (unsigned)locb[ck[k]] + rk[k];
                 BinRec<T, 3> r;
                 r.v[0] = pu[k]; r.v[1] = pv[k]; r.v[2] = pw[k];
                 r.v[3] = tag_word<T>((unsigned)(lo + p) | tg[k]);   // where bin_unpermute_stream finds the result, and the span key
@@ -738,17 +820,13 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
                 lpos[lo + i] = (unsigned short)p;
             }
         }
-#pragma unroll
-        for (int i = 0; i < NEXT_PPT; ++i) {
-            const int b = (int)threadIdx.x * per + i;
-            if (i < per && b < cells) lcnt[b] = g[i];             // the counts are dead: the slot holds the run's global start now
-        }
-        if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);     // in flight during the store phase
         __syncthreads();
         for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
             const unsigned b = sbin[p];
-            rec[lcnt[b] + ((unsigned)p - locb[b])] = srec[p];
+            rec[cursor[b] + ((unsigned)p - (unsigned)locb[b])] = srec[p];
         }
+        __syncthreads();                                          // every record of the chunk has read its cursor
+        for (int i = threadIdx.x; i < cells; i += blockDim.x) cursor[i] += lcnt[i];
     }
 }
 

@@ -58,15 +58,14 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     const long long piece = std::min(n, (((n + pieces - 1) / pieces) + 1023) / 1024 * 1024);
     // chunk of the scatter / un-permute: records (+ a 16-bit bin each) beside two bin tables and the span tables
     const size_t tabs_b = (span_lds_bytes<T, 3>(d, td) + 15) & ~(size_t)15;
-    const size_t bins_b = (8 * (size_t)bp.cells + 15) & ~(size_t)15;
-    if (bins_b + tabs_b + 1024 > s->lds_max || bp.cells > BIN_MAX_WC_CELLS) return BSK_ERR_UNSUPPORTED;
+    const size_t bins_b = (10 * (size_t)bp.cells + 15) & ~(size_t)15;
+    if (bins_b + tabs_b + 1024 > s->lds_max || bp.cells > BIN_MAX_CELLS) return BSK_ERR_UNSUPPORTED;
     const size_t out_sz = (4 * sizeof(T) + 15) / 16 * 16;          // BinOut<T, ND <= 4>
     long long chunk_max = (long long)((s->lds_max - bins_b - tabs_b - 256) / (sizeof(BinRec<T, 3>) + 2)) / 1024 * 1024;
     chunk_max = std::min<long long>(chunk_max, (long long)(s->lds_max / out_sz) / 1024 * 1024);
     chunk_max = std::min<long long>(chunk_max, 1024 * WC_PPT);
     static const int env_wc = getenv("BSK_WC_CHUNK") ? atoi(getenv("BSK_WC_CHUNK")) : 0;                  // measurement knobs
     static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;
-    static const int env_tot = getenv("BSK_TOT_GRID") ? atoi(getenv("BSK_TOT_GRID")) : 0;
     if (env_wc > 0) chunk_max = std::min<long long>(chunk_max, std::max(1024, env_wc / 1024 * 1024));
     if (chunk_max < 2048) return BSK_ERR_UNSUPPORTED;
     const size_t lds_tot = ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15) + 4 * (size_t)bp.cells;
@@ -75,13 +74,18 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_lpos = 0, o_rec = o_lpos + up(2 * (size_t)piece), o_tmp = o_rec + up(sizeof(BinRec<T, 3>) * (size_t)piece);
     const size_t o_tot = o_tmp + up(out_sz * (size_t)piece), o_start = o_tot + up(4 * (size_t)(bp.cells + 1));
-    const size_t o_fill = o_start + up(4 * (size_t)bp.cells), total = o_fill + up(4 * (size_t)bp.cells);
+    const size_t o_rows = o_start + up(4 * (size_t)bp.cells), total = o_rows + up(4 * (size_t)bp.cells * s->num_cu);
     HIPCHK(s->bin_ws.reserve(total));
     char *ws = static_cast<char *>(s->bin_ws.p);
     unsigned short *lpos = reinterpret_cast<unsigned short *>(ws + o_lpos);
     BinRec<T, 3> *rec = reinterpret_cast<BinRec<T, 3> *>(ws + o_rec);
-    unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot), *done = tot + bp.cells;
-    unsigned *start = reinterpret_cast<unsigned *>(ws + o_start), *fill = reinterpret_cast<unsigned *>(ws + o_fill);
+    unsigned *tot = reinterpret_cast<unsigned *>(ws + o_tot);
+    if (!s->ticket) {                                             // the tickets start at zero and every user leaves them at zero
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&s->ticket), 256));
+        HIPCHK(hipMemset(s->ticket, 0, 256));
+    }
+    unsigned *done = s->ticket;
+    unsigned *start = reinterpret_cast<unsigned *>(ws + o_start), *rows = reinterpret_cast<unsigned *>(ws + o_rows);
     const T *tab = static_cast<const T *>(s->tab);
     const T *aos = static_cast<const T *>(s->coef_aos);
     const bool reuse = s->bin_reuse && pieces == 1;               // later derivative passes of a jacobian find the batch sorted
@@ -96,21 +100,20 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
         Params<T> pp = prm;
         for (int iv = 0; iv < 3; ++iv) pp.p[iv] = prm.p[iv] + off;
         bp.chunks = (int)((np + chunk_max - 1) / chunk_max);
-        bp.chunk = (np + bp.chunks - 1) / bp.chunks;
+        bp.chunk = ((np + bp.chunks - 1) / bp.chunks + 7) & ~7ll;        // multiples of 8 points: chunks keep the batch's 16-byte alignment
         bp.ranges = bp.rlen = 1;
         const int pgrid = std::min(bp.chunks, s->num_cu);
         stage_mark(s, st, "start", true);
         if (!reuse) {
-            HIPCHK(hipMemsetAsync(tot, 0, 4 * (size_t)(bp.cells + 1), st));
-            const long long vecs = (np + 16 / (long long)sizeof(T) - 1) / (16 / (long long)sizeof(T));
-            const int tgrid = (int)std::max<long long>(1, std::min<long long>((vecs + 2047) / 2048, (long long)s->num_cu * (env_tot > 0 ? env_tot : 2)));
             HIPCHK(allow_lds(bin_totals<T>, lds_tot));
-            hipLaunchKernelGGL((bin_totals<T>), dim3(tgrid), dim3(1024), lds_tot, st, d, td, bp, tab, s->lut, pp, np, tot, start, fill, done);
+            hipLaunchKernelGGL((bin_totals<T>), dim3(pgrid), dim3(1024), lds_tot, st, d, td, bp, tab, s->lut, pp, np, rows);
             stage_mark(s, st, "bin_totals");
+            hipLaunchKernelGGL(bin_starts, dim3((bp.cells + 63) / 64), dim3(1024), 0, st, bp.cells, pgrid, rows, tot, start, done);
+            stage_mark(s, st, "bin_starts");
             const size_t lds_s = bins_b + (((size_t)bp.chunk * (sizeof(BinRec<T, 3>) + 2) + 15) & ~(size_t)15) + tabs_b;
             HIPCHK(allow_lds(bin_scatter_tag<T>, lds_s));
-            hipLaunchKernelGGL((bin_scatter_tag<T>), dim3(pgrid), dim3(1024), lds_s, st, bp, pp, np, off, fill, rec, lpos, d, td, tab, s->lut,
-                               dest_bits, s->bad);
+            hipLaunchKernelGGL((bin_scatter_tag<T>), dim3(pgrid), dim3(1024), lds_s, st, bp, pp, np, off, rows, start, rec, lpos, d, td, tab,
+                               s->lut, dest_bits, s->bad);
             stage_mark(s, st, "bin_scatter_tag");
         }
         const int cgrid = (int)std::max<long long>(1, std::min<long long>((np + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : 4)));
@@ -220,9 +223,6 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         const T *tab = static_cast<const T *>(s->tab);
         const T *aos = static_cast<const T *>(s->coef_aos);
         const int egrid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)s->num_cu * 8));
-        // eval_cellsort: two 512-lane workgroups per CU, two rounds
-        static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;                 // measurement knob: workgroups per CU
-        const int cgrid = (int)std::max<long long>(1, std::min<long long>((n + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : 4)));
         // rows of one cell staged in LDS (eval_binned_lds) when they fit beside the axis tables twice per CU
         const size_t rows_b = (size_t)((1 << bp.sh0) + s->order[0] - 1) * (NIND == 3 ? (size_t)((1 << bp.sh1) + s->order[1] - 1) : 1);
         const size_t bundle_b = ((rows_b * (size_t)s->ncoef[NIND - 1] * s->nDep * sizeof(T)) + 15) & ~(size_t)15;

@@ -80,6 +80,7 @@ struct bsk_spline_s {
     size_t lds_max = 160 * 1024;
     DevBuf in_ws, out_ws, aux_ws;       // staging for BSK_HOST calls and grid tables
     DevBuf bin_ws;                      // cell-order evaluation (bsk_binned.hpp)
+    unsigned *ticket = nullptr;         // zero-initialised counters of the cell-order pipeline's "last workgroup" hand-overs
     bool bin_reuse = false;             // the batch in bin_ws is already sorted (later derivative passes of a jacobian)
     DevBuf curv_ws;                     // derivative passes of the non-fused curvature
     std::vector<unsigned char> tab_host; // host copy of the axis table (bsk_tessellate compares knots of a batch)
