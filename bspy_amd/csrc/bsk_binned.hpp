@@ -687,9 +687,15 @@ __global__ __launch_bounds__(1024) void bin_starts(const int cells, const int G,
         }
         if (grp == 0) tot[b] = total;
     }
-    __threadfence();
+    // hand-over (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave drains its stores, the workgroup
+    // meets, ONE lane releases at agent scope and takes the ticket (a fence per wave costs microseconds each)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
     __syncthreads();
     if (!s_last) return;
     // last workgroup: the totals of the others were written and released (__threadfence) before their tickets
@@ -779,15 +785,21 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
         __syncthreads();                                          // the previous chunk's store phase is done with LDS (first: tables, cursors staged)
         for (int i = threadIdx.x; i < cells; i += blockDim.x) lcnt[i] = 0u;
         __syncthreads();
+        // bins and span keys of the lane's 8 points: straight-line code over all of them (a lane past the chunk's end
+        // holds a copy of its last point), so that the 8 chains of dependent LDS reads interleave; only the domain
+        // record and the histogram update are predicated
         unsigned ck[WC_PPT], rk[WC_PPT], tg[WC_PPT];
 #pragma unroll
+        for (int k = 0; k < WC_PPT; ++k) ck[k] = (unsigned)bin_of<T>(sl, d, td, bp, pu[k], pv[k]);
+#pragma unroll
+        for (int k = 0; k < WC_PPT; ++k)
+            tg[k] = (unsigned)(find_span_lut<T>(sl.kn[2], sl.lut, td, 2, d.lo[2], d.ncoef[2], pw[k]) - d.order[2]) << dest_bits;
+#pragma unroll
         for (int k = 0; k < WC_PPT; ++k) {
-            ck[k] = 0u; rk[k] = 0u; tg[k] = 0u;
+            rk[k] = 0u;
             if (k * 1024 + (int)threadIdx.x < cnt) {
                 const bool outside = (pu[k] < d.lo[0]) | (pu[k] > d.hi[0]) | (pv[k] < d.lo[1]) | (pv[k] > d.hi[1]) | (pw[k] < d.lo[2]) | (pw[k] > d.hi[2]);
                 if (outside) record_bad(bad, base + lo + k * 1024 + (long long)threadIdx.x);
-                ck[k] = (unsigned)bin_of<T>(sl, d, td, bp, pu[k], pv[k]);
-                tg[k] = (unsigned)(find_span_lut<T>(sl.kn[2], sl.lut, td, 2, d.lo[2], d.ncoef[2], pw[k]) - d.order[2]) << dest_bits;
                 rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
             }
         }
@@ -823,7 +835,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
         __syncthreads();
         for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
             const unsigned b = sbin[p];
-            rec[cursor[b] + ((unsigned)p - (unsigned)locb[b])] = srec[p];
+            const unsigned slot = cursor[b] + ((unsigned)p - (unsigned)locb[b]);
+            rec[slot < (unsigned long long)N ? slot : (unsigned)(N - 1)] = srec[p];     // (clamped: cursor comes from other kernels' tables)
         }
         __syncthreads();                                          // every record of the chunk has read its cursor
         for (int i = threadIdx.x; i < cells; i += blockDim.x) cursor[i] += lcnt[i];
@@ -1333,7 +1346,9 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 const int idx = i * CS_BLOCK + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
-                    key[i] = (int)(word_tag<T>((T)rc[i][3]) >> dest_bits);             // found by the scatter kernel
+                    // found by the scatter kernel.  (Clamped: a tag is DATA from another kernel; no index formed from it
+                    // may leave its array - histogram here, bundle and tmp below.)
+                    key[i] = min((int)(word_tag<T>((T)rc[i][3]) >> dest_bits), S2 - 1);
                     rank[i] = atomicAdd(&hc[key[i]], 1u);
                 }
             }
@@ -1385,7 +1400,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 const bool live = q < total;
                 const BinRec<T, 3> r = srec[live ? q : total - 1];
                 const unsigned tag = word_tag<T>(r.v[3]);
-                const int ix2 = (int)(tag >> dest_bits);
+                const int ix2 = min((int)(tag >> dest_bits), S2 - 1);
                 const unsigned dest = tag & dest_mask;
                 T b[3][O];
                 SpanTab<T, O> st2;
@@ -1430,7 +1445,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     int pad[3] = {0, 0, 0};
                     window_contract<T, 3, O, ND, false>(bun + (long long)ix2 * ND, O * ncl, ncl, pad, b, res);
                 }
-                if (live && dest != dest_mask) {
+                if (live && (long long)dest < N) {             // padding lanes carry dest_mask >= N; nothing else can pass either
                     BinOut<T, ND> o;
 #pragma unroll
                     for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);

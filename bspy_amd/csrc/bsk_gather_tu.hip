@@ -53,10 +53,7 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     const TileDesc<T> &td = tile_of<T>(s);
     const int S2 = s->ncoef[2] - s->order[2] + 1;
     const int dest_bits = S2 <= 64 ? 26 : 24;
-    const long long piece_max = (((1ll << dest_bits) - 1) / 1024) * 1024;
-    const long long pieces = (n + piece_max - 1) / piece_max;
-    const long long piece = std::min(n, (((n + pieces - 1) / pieces) + 1023) / 1024 * 1024);
-    // chunk of the scatter / un-permute: records (+ a 16-bit bin each) beside two bin tables and the span tables
+    // chunk of the scatter / un-permute: records (+ a 16-bit bin each) beside the bin tables and the span tables
     const size_t tabs_b = (span_lds_bytes<T, 3>(d, td) + 15) & ~(size_t)15;
     const size_t bins_b = (10 * (size_t)bp.cells + 15) & ~(size_t)15;
     if (bins_b + tabs_b + 1024 > s->lds_max || bp.cells > BIN_MAX_CELLS) return BSK_ERR_UNSUPPORTED;
@@ -68,6 +65,9 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;
     if (env_wc > 0) chunk_max = std::min<long long>(chunk_max, std::max(1024, env_wc / 1024 * 1024));
     if (chunk_max < 2048) return BSK_ERR_UNSUPPORTED;
+    const long long piece_max = (((1ll << dest_bits) - 1) / 1024) * 1024;
+    const long long pieces = (n + piece_max - 1) / piece_max;
+    const long long piece = std::min(n, (((n + pieces - 1) / pieces) + 1023) / 1024 * 1024);
     const size_t lds_tot = ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15) + 4 * (size_t)bp.cells;
     if (lds_tot > s->lds_max / 2) return BSK_ERR_UNSUPPORTED;
 

@@ -12,6 +12,7 @@ import weakref
 import numpy as np
 
 from . import _native as nv
+from .result_pool import default_pool
 
 _default_device = None
 
@@ -131,7 +132,9 @@ class DeviceSpline:
 
     def _host_out(self, out, shape):
         if out is None:
-            return np.empty(shape, self.dtype)
+            # a fresh array, as the reference returns - its memory recycled from results the caller has dropped
+            # (result_pool.py: first-touch page faults are most of a large NumPy call)
+            return default_pool().empty(shape, self.dtype)
         if not isinstance(out, np.ndarray) or out.dtype != self.dtype or out.shape != shape or not out.flags.c_contiguous:
             raise ValueError(f"out must be a C-contiguous {np.dtype(self.dtype).name} array of shape {shape}")
         return out
@@ -163,7 +166,7 @@ class DeviceSpline:
         """points: nInd arrays of N values -> ndarray (max(nInd, nDep), N) of normals
         (|nInd - nDep| must be 1)."""
         ps, n = self._host_params(points)
-        out = np.empty((max(self.nInd, self.nDep), n), self.dtype)
+        out = default_pool().empty((max(self.nInd, self.nDep), n), self.dtype)
         bad = ctypes.c_int64(-1)
         st = nv.lib().bsk_normal(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
                                  1 if normalize else 0, 1 if negate else 0, out.ctypes.data, None, ctypes.byref(bad))
@@ -190,7 +193,7 @@ class DeviceSpline:
         """points: nInd arrays of N values -> ndarray (N,): curvature of a curve (nDep >= 2) or
         Gaussian curvature of a surface in 3-D."""
         ps, n = self._host_params(points)
-        out = np.empty(n, self.dtype)
+        out = default_pool().empty((n,), self.dtype)
         bad = ctypes.c_int64(-1)
         st = nv.lib().bsk_curvature(self._handle, nv.ptr_array([p.ctypes.data for p in ps]), n, nv.BSK_HOST,
                                     out.ctypes.data, None, ctypes.byref(bad))
@@ -215,7 +218,7 @@ class DeviceSpline:
             raise ValueError(f"Incorrect number of parameter values: {len(axes)}")
         gs = [np.ascontiguousarray(a, self.dtype).ravel() for a in axes]
         shape = tuple(g.size for g in gs)
-        out = np.empty((self.nDep, *shape), self.dtype)
+        out = default_pool().empty((self.nDep, *shape), self.dtype)
         bad = ctypes.c_int64(-1)
         ng = (ctypes.c_int64 * max(self.nInd, 1))(*shape)
         st = nv.lib().bsk_evaluate_grid(self._handle, nv.int_array(wrt) if wrt is not None else None,
@@ -354,8 +357,8 @@ def tessellate(patches, axes, normals=True, normalize=True, negate=False, out=No
         return (pos, nrm) if normals else pos
     gs = [np.ascontiguousarray(a, first.dtype).ravel() for a in axes]
     shape = (len(patches), 3, gs[0].size, gs[1].size)
-    pos = np.empty(shape, first.dtype)
-    nrm = np.empty(shape, first.dtype) if normals else None
+    pos = default_pool().empty(shape, first.dtype)
+    nrm = default_pool().empty(shape, first.dtype) if normals else None
     ng = (ctypes.c_int64 * 2)(shape[2], shape[3])
     st = nv.lib().bsk_tessellate(handles, len(patches), nv.ptr_array([g.ctypes.data for g in gs]), ng, nv.BSK_HOST,
                                  int(bool(normalize)), int(bool(negate)), pos.ctypes.data,
@@ -423,7 +426,7 @@ class MultiDeviceSpline:
         ps = [np.ascontiguousarray(p, self.dtype).ravel() for p in points]
         n = ps[0].size
         rows = self.nDep * self.nInd if jac else self.nDep
-        out = np.empty((rows, n), self.dtype)
+        out = default_pool().empty((rows, n), self.dtype)
         bad = ctypes.c_int64(-1)
         outs = nv.ptr_array([out.ctypes.data])
         if jac:

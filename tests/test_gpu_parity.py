@@ -751,10 +751,10 @@ def test_normal_against_reference(name, golden_parity):
         assert out.shape == ref.shape
         assert np.array_equal(np.isnan(out), np.isnan(ref)), (name, key)
         if not np.isnan(ref).all():
-            assert np.nanmax(np.abs(out - ref)) <= tol * max(1.0, float(np.nanmax(np.abs(ref)))), (name, key)
+            observe(f"normal vs reference, {'fp32' if tol > 1e-9 else 'fp64'}", np.nanmax(np.abs(out - ref)) / max(1.0, float(np.nanmax(np.abs(ref)))), tol)
         orc, bad = oracle.c_normal(c.order, c.nCoef, c.knots, c.coefs, pts, normalize, bool(meta))
         if not np.isnan(orc).all():
-            assert np.nanmax(np.abs(out - orc)) <= tol * max(1.0, float(np.nanmax(np.abs(orc))))
+            observe(f"normal vs oracle, {'fp32' if tol > 1e-9 else 'fp64'}", np.nanmax(np.abs(out - orc)) / max(1.0, float(np.nanmax(np.abs(orc)))), tol)
     if c.order[0] > 1:
         s = Spline(c.nInd, c.nDep, c.order, c.nCoef, c.knots, c.coefs)
         one = s.normal([float(p[3]) for p in c.points])               # single point, reference call style
@@ -885,12 +885,12 @@ def test_curvature_against_reference(name, golden_parity):
     if ok.any():
         kind = "fp32" if f32 else "fp64"
         err = np.abs(out[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok]))
-        observe(f"curvature vs reference, {kind} [{name}]", err.max(), 2e-3 if f32 else 1e-8)
+        observe(f"curvature vs reference, {kind} [{name}]", err.max(), 5e-4 if f32 else 1e-11)
         orc, _ = oracle.c_curvature(c.order, c.nCoef, c.knots, c.coefs, pts)
         err = np.abs(out[ok] - orc[ok]) / np.maximum(1.0, np.abs(orc[ok]))
-        observe(f"curvature vs oracle, {kind} [{name}]", err.max(), 2e-3 if f32 else 1e-8)
+        observe(f"curvature vs oracle, {kind} [{name}]", err.max(), 1e-4 if f32 else 1e-11)
         one = s.curvature([float(p[5]) for p in c.points])            # single point
-        observe(f"curvature, single point vs reference, {kind}", abs(one - ref[5]) / max(1.0, abs(ref[5])), 2e-3 if f32 else 1e-8)
+        observe(f"curvature, single point vs reference, {kind}", abs(one - ref[5]) / max(1.0, abs(ref[5])), 2e-5 if f32 else 1e-11)
 
 
 def test_reference_curvature_pin(golden_tables):
@@ -953,19 +953,20 @@ def test_spline_block_against_reference(case):
     ref = g[f"{c.name}/evaluate"]
     assert np.abs(full[:, :m] - ref).max() <= tol * max(1.0, np.abs(ref).max())
     orc = _block_oracle(c, "evaluate")
-    assert np.abs(full - orc).max() <= tol * max(1.0, np.abs(orc).max())
+    kind = "fp32" if f32 else "fp64"
+    observe(f"SplineBlock evaluate vs oracle, {kind}", np.abs(full - orc).max() / max(1.0, np.abs(orc).max()), tol)
     for w in c.wrts:
         got = blk.derivative(w, c.points)
         ref = g[f"{c.name}/wrt_" + "_".join(map(str, w))]
-        assert np.abs(got[:, :m] - ref).max() <= 100 * tol * max(1.0, np.abs(ref).max())
+        observe(f"SplineBlock derivative vs reference, {kind}", np.abs(got[:, :m] - ref).max() / max(1.0, np.abs(ref).max()), 100 * tol)
         orc = _block_oracle(c, "evaluate", w)
-        assert np.abs(got - orc).max() <= 100 * tol * max(1.0, np.abs(orc).max())
+        observe(f"SplineBlock derivative vs oracle, {kind}", np.abs(got - orc).max() / max(1.0, np.abs(orc).max()), 100 * tol)
     jac = blk.jacobian(c.points)
     ref = g[f"{c.name}/jacobian"]
     assert jac.shape == (c.nDep, c.nInd, len(c.points[0]))
-    assert np.abs(jac[:, :, :m] - ref).max() <= 10 * tol * max(1.0, np.abs(ref).max())
+    observe(f"SplineBlock jacobian vs reference, {kind}", np.abs(jac[:, :, :m] - ref).max() / max(1.0, np.abs(ref).max()), 10 * tol)
     orc = _block_oracle(c, "jacobian")
-    assert np.abs(jac - orc).max() <= 10 * tol * max(1.0, np.abs(orc).max())
+    observe(f"SplineBlock jacobian vs oracle, {kind}", np.abs(jac - orc).max() / max(1.0, np.abs(orc).max()), 10 * tol)
     # CUDA tensors in -> tensors out, same numbers; broadcasting shapes are kept
     dev = [torch.as_tensor(p, device="cuda") for p in c.points]
     td = blk.evaluate(dev)
@@ -1004,7 +1005,7 @@ def test_tessellate_against_reference(golden_tables):
         ref = g[f"{name}/normals"]
         ok = np.isfinite(ref) & np.isfinite(nrm)
         assert ok.mean() > 0.8
-        observe(f"tessellation unit normals vs reference, {'fp32' if f32 else 'fp64'} [{name}]", np.abs(nrm[ok] - ref[ok]).max(), 2e-3 if f32 else 1e-9)
+        observe(f"tessellation unit normals vs reference, {'fp32' if f32 else 'fp64'} [{name}]", np.abs(nrm[ok] - ref[ok]).max(), 2e-5 if f32 else 1e-12)
         # degenerate points (zero-length cross product): NaN in the reference and here
         assert np.array_equal(np.isnan(ref).any(axis=1), np.isnan(nrm).any(axis=1)) or f32
         # positions only; area-scaled and negated normals against the oracle
@@ -1014,7 +1015,7 @@ def test_tessellate_against_reference(golden_tables):
         uu, vv = [a.reshape(-1).astype(np.float64) for a in np.meshgrid(u, v, indexing="ij")]
         o, c, k, cf = patches[1]
         orc, _ = oracle.c_normal(o, c, k, cf, [uu.astype(dt), vv.astype(dt)], False, True)
-        observe(f"tessellation area normals vs oracle, {'fp32' if f32 else 'fp64'}", np.abs(raw[1].reshape(3, -1) - orc).max() / max(1.0, np.abs(orc).max()), 1e-3 if f32 else 1e-10)
+        observe(f"tessellation area normals vs oracle, {'fp32' if f32 else 'fp64'}", np.abs(raw[1].reshape(3, -1) - orc).max() / max(1.0, np.abs(orc).max()), 2e-5 if f32 else 1e-12)
         # device tensors in -> tensors out, same numbers; the single-patch grid call agrees bitwise
         dp, dn = bspy_amd.tessellate_tables(tabs, (torch.as_tensor(u, device="cuda"), torch.as_tensor(v, device="cuda")))
         assert dp.is_cuda and np.array_equal(dp.cpu().numpy(), pos) and np.array_equal(dn.cpu().numpy(), nrm, equal_nan=True)
@@ -1058,6 +1059,46 @@ def test_tessellate_full_teapot(golden_tables):
         assert np.nanmax(np.where(inner, cosang, 0.0)) <= 0.05
 
 
+def test_cfg4_full_size(golden_tables):
+    """BASELINE configs[3] at its real size: the 32 teapot patches on a dense 2048 x 2048 grid each, positions and unit
+    normals from ONE bsk_tessellate call, device resident.  Every patch equals its own single-patch grid call; the
+    oracle on a 33 x 33 sub-grid of every patch; the four corner points of every patch are the corner points of the
+    reference's 16 x 16 grid (tests/golden: teapot_grid16 - linspace(0, 1, 2048) and linspace(0, 1, 16) share no
+    other point); determinism."""
+    torch = pytest.importorskip("torch")
+    patches = cases.teapot_patches(golden_tables)
+    tabs = [DeviceSpline(o, c, k, cf, np.float32) for (o, c, k, cf) in patches]
+    side = 2048
+    g = torch.linspace(0, 1, side, dtype=torch.float32, device="cuda")
+    pos, nrm = bspy_amd.tessellate_tables(tabs, (g, g))
+    assert tuple(pos.shape) == (32, 3, side, side) and pos.dtype == torch.float32
+    for p in (0, 11, 31):
+        one = tabs[p].evaluate_grid_device([g, g])
+        observe("cfg4 full size: batch vs single-patch grid call, fp32", float((one - pos[p]).abs().max()), 2e-6)
+        del one
+    sub = torch.arange(0, side, 64, device="cuda").tolist() + [side - 1]
+    gs = g[sub].cpu().numpy()
+    uu, vv = [a.reshape(-1) for a in np.meshgrid(gs, gs, indexing="ij")]
+    worst = 0.0
+    for p, (o, c, k, cf) in enumerate(patches):
+        orc, bad = oracle.c_evaluate(o, c, k, cf, [0, 0], [uu, vv])
+        assert bad == -1
+        got = pos[p][:, sub][:, :, sub].reshape(3, -1).cpu().numpy()
+        worst = max(worst, float(np.abs(got - orc).max() / _scale(orc)))
+    observe("cfg4 full size: 33 x 33 sub-grid of every patch vs oracle, fp32", worst, 2e-5)
+    ref16 = golden_tables["teapot_grid16"]
+    corners = pos[:, :, [0, 0, side - 1, side - 1], [0, side - 1, 0, side - 1]].cpu().numpy()
+    ref_c = ref16[:, :, [0, 0, 15, 15], [0, 15, 0, 15]]
+    observe("cfg4 full size: patch corners vs the reference's 16 x 16 grid, fp32", float(np.abs(corners - ref_c).max() / _scale(ref_c)), 2e-6)
+    ok = torch.isfinite(nrm).all(dim=1)
+    assert float(ok.float().mean()) > 0.99
+    ln = (nrm.double() ** 2).sum(dim=1).sqrt()
+    assert float((ln[ok] - 1.0).abs().max()) <= 1e-5
+    pos2 = bspy_amd.tessellate_tables(tabs, (g, g), normals=False)
+    observe("cfg4 full size: positions-only call vs positions + normals, fp32", float((pos2 - pos).abs().max()), 2e-6)
+    assert torch.equal(pos2, bspy_amd.tessellate_tables(tabs, (g, g), normals=False))
+
+
 def test_fused_curvature_orders_and_sizes():
     """curv_rowrot (fused Gaussian curvature on the LDS image) for both template orders against the
     oracle, on odd batch sizes; the piecewise bilinear case has S_uu = S_vv = 0."""
@@ -1072,7 +1113,7 @@ def test_fused_curvature_orders_and_sizes():
             got = t.curvature(pts)
             ok = np.isfinite(orc)
             assert ok.mean() > 0.9 and np.array_equal(ok, np.isfinite(got))
-            observe(f"fused curvature vs oracle, order {order[0]}", np.abs(got[ok] - orc[ok]).max() / max(1.0, np.abs(orc[ok]).max()), 1e-9)
+            observe(f"fused curvature vs oracle, order {order[0]}", np.abs(got[ok] - orc[ok]).max() / max(1.0, np.abs(orc[ok]).max()), 1e-11)
         bad = [rng.random(100), rng.random(100)]
         bad[1][42] = 1.5
         with pytest.raises(bspy_amd.DomainError) as e:
@@ -1171,7 +1212,7 @@ def test_random_large_tables_against_oracle():
         coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
         assert coefs.nbytes > 170_000
         t = DeviceSpline(order, ncoef, knots, coefs, dt)
-        tol = 5e-5 if dt == np.float32 else 1e-11
+        tol = 2e-5 if dt == np.float32 else 1e-12
         for n in (4_097, 270_001):
             pts = [rng.random(n).astype(dt) for _ in range(nind)]
             w = [int(rng.integers(0, 2)) for _ in range(nind)]
@@ -1180,7 +1221,7 @@ def test_random_large_tables_against_oracle():
                 got = t.evaluate(pts, ww)
                 orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, ww, [p[idx] for p in pts])
                 assert bad == -1
-                observe(f"random large tables vs oracle, {'fp32' if dt == np.float32 else 'fp64'}", np.abs(got[:, idx] - orc).max() / _scale(orc), 30 * tol)
+                observe(f"random large tables vs oracle, {'fp32' if dt == np.float32 else 'fp64'}", np.abs(got[:, idx] - orc).max() / _scale(orc), tol)
         t.close()
 
 

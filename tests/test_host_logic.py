@@ -235,6 +235,41 @@ def test_sharded_evaluator_gloo_world2(tmp_path):
         assert f"rank {r} ok" in out
 
 
+def test_result_pool_recycles_only_dead_results():
+    """Large host results reuse the memory of results the caller has DROPPED (no first-touch page faults), and never
+    memory that any array still refers to: the rows of `x, y, z = s(u, v)` outlive the 2-D result they are views of."""
+    import gc
+    from bspy_amd.result_pool import ResultPool, MIN_BYTES
+    pool = ResultPool()
+    small = pool.empty((3, 10), np.float64)
+    assert small.base is None and pool.allocated == 0                      # small results: plain arrays
+    shape = (3, MIN_BYTES // 8)
+    a = pool.empty(shape, np.float64)
+    assert a.shape == shape and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable and a.flags.aligned
+    addr = a.ctypes.data
+    a[:] = 7.0
+    x, y, z = a[0], a[1], a[2]                                             # the reference returns a tuple of rows
+    del a
+    gc.collect()
+    b = pool.empty(shape, np.float64)
+    assert b.ctypes.data != addr and pool.recycled == 0                    # rows alive: their memory is NOT handed out
+    b[:] = 1.0
+    assert float(x[0]) == 7.0 and float(z[-1]) == 7.0
+    del x, y
+    gc.collect()
+    c = pool.empty(shape, np.float32)                                      # still one row alive
+    assert c.ctypes.data != addr
+    del z
+    gc.collect()
+    d = pool.empty(shape, np.float64)
+    assert d.ctypes.data == addr and pool.recycled == 1                    # the last view is gone: recycled
+    e = pool.empty((2, 5, MIN_BYTES // 8), np.float64)                     # larger than anything free: new memory
+    assert e.shape == (2, 5, MIN_BYTES // 8) and pool.recycled == 1
+    del b, c, d, e
+    gc.collect()
+    assert len(pool._free) <= 4
+
+
 def test_json_round_trip_and_reference_files(tmp_path):
     """The reference's JSON format as an input format: files from the reference's
     own test suite load, and save -> load reproduces the spline."""
