@@ -44,7 +44,7 @@ BYTES_PER_EVAL = {"evaluate": 40, "derivative": 40, "jacobian": 64, "normal": 40
 FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak = fp32 MFMA peak (MI355X_MICROARCH.md)
 CFG5_FLOP_PER_POINT = 1450     # algorithmic fp32 flop per cfg5 point
 CFG5_MFMA_FLOP_PER_POINT = 1000  # the part of them the 4x4x1 MFMAs carry: 125 control points x 4 dependents x 2
-PROFILE_DIR = "profiles/r02_eval_uni"    # rocprofv3 summaries of this command (kernel trace + PMC passes)
+PROFILE_DIR = "profiles/r03_eval_uni"    # rocprofv3 summaries of this command (kernel trace + PMC passes)
 
 
 def cpu_model():
@@ -192,8 +192,22 @@ def other_configs(torch, tables, u, v, n):
         t5 = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt)
         p5 = [torch.rand(n, dtype=torch.float32, device=u.device) for _ in range(3)]
         o5 = torch.empty((4, n), dtype=torch.float32, device=u.device)
-        r = row(timed(torch, lambda: t5.evaluate_device(p5, out=o5, check=False), 10), n, 28)
+        f5 = lambda: t5.evaluate_device(p5, out=o5, check=False)
+        r = row(timed(torch, f5, 10), n, 28)
         r["kernel"] = t5.last_kernel()
+        # the bounds that apply to cfg5 (not HBM): fp32 ALU and the matrix pipe, and where the time goes
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from cfg5_stages import stage_times
+        st_ms = stage_times(t5, f5, reps=10)
+        ev = sum(v for k, v in st_ms.items() if k.startswith("eval"))
+        r.update({"points": n, "stages_ms": {k: round(v, 4) for k, v in st_ms.items()},
+                  "sort_ms": round(sum(v for k, v in st_ms.items() if not k.startswith("eval")), 4), "eval_ms": round(ev, 4),
+                  "alu_frac": round(CFG5_FLOP_PER_POINT * n / (r["ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                  "alu_frac_of_eval_kernel": round(CFG5_FLOP_PER_POINT * n / (ev * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if ev else None,
+                  "mfma_frac_of_eval_kernel": round(CFG5_MFMA_FLOP_PER_POINT * n / (ev * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4) if ev else None,
+                  "note": "alu_frac: 1450 algorithmic fp32 flop per point against the 157.3 TFLOP/s vector peak; mfma_frac: the 1000 flop per "
+                          "point carried by v_mfma_f32_4x4x1 against the fp32 matrix peak (also 157.3), over the evaluation kernel's time; "
+                          "stages: HIP events between the pipeline's kernels (bsk_debug_stage_times)"})
         res["cfg5_trivariate_f32"] = r
         t5.domain_status()
     except Exception as e:  # diagnostic only: never fail the headline line

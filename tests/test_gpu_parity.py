@@ -587,6 +587,10 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
         kind = "fp32" if dt == np.float32 else "fp64"
         if regrouped:
             observe(f"cell order vs gather kernel, regrouped, {kind}", np.abs(out - ref_plain).max() / _scale(ref_plain), tol)
+        elif t.last_kernel() == "eval_slab2":
+            # surfaces streamed through LDS (bsk_slab.hpp): the gather kernel's operations in the same order, but its
+            # table reads are explicit and hipcc contracts multiply-adds around them differently: a few ulp
+            observe(f"eval_slab2 vs gather kernel, {kind}", np.abs(out - ref_plain).max() / _scale(ref_plain), 1e-5 if dt == np.float32 else 1e-13)
         else:
             assert np.array_equal(out, ref_plain), (shape, w)
         orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, w, [p[sample] for p in pts])
