@@ -338,16 +338,15 @@ static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long lon
     sp.off_slab = (unsigned)(off + up16((size_t)sp.snk * slicebytes));
     sp.total = (unsigned)(sp.off_slab + up16((size_t)sp.rows * rowbytes));
     if (sp.total > lds_wg) return BSK_ERR_UNSUPPORTED;
-    // chunk-private scratch of the ordered points: {u, v} and batch position | span
+    // chunk-private scratch of the order: batch position | span of every point
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return BSK_ERR_UNSUPPORTED;                               // the workspace may have to be (re)allocated
     }
-    const size_t pts_b = (sizeof(SlabPt<T>) * (size_t)n + 255) & ~(size_t)255;
-    HIPCHK(s->bin_ws.reserve(pts_b + 4 * (size_t)n));
-    SlabPt<T> *spts = reinterpret_cast<SlabPt<T> *>(s->bin_ws.p);
-    unsigned *sidx = reinterpret_cast<unsigned *>(static_cast<char *>(s->bin_ws.p) + pts_b);
+    HIPCHK(s->bin_ws.reserve(4 * (size_t)n + 256));
+    SlabPt<T> *spts = nullptr;                                    // (the points are read again from the caller's arrays)
+    unsigned *sidx = reinterpret_cast<unsigned *>(s->bin_ws.p);
     const long long nchunks = (n + SLAB_CHUNK - 1) / SLAB_CHUNK;
     const int grid = (int)std::min<long long>(nchunks, (long long)s->num_cu);
     static const int slab_dbg = getenv("BSK_SLAB_DBG") ? atoi(getenv("BSK_SLAB_DBG")) : 0;     // timing-only switches (tools/)

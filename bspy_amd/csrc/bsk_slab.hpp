@@ -8,10 +8,11 @@
 // of rows of the control-point-major table, and the whole table is only a few hundred KB.  So nothing is sorted
 // globally: one persistent 1024-lane workgroup per CU takes chunks of 8192 points and
 //   1. loads the chunk, finds the spans of the first variable, and orders the chunk BY PASS (pass = block of `spp`
-//      consecutive spans whose rows fit the LDS slab) - wave ballots, no atomics; the ordered points go to a
-//      chunk-private scratch in global memory ({u, v} and batch position | span), which the same workgroup reads
-//      back pass by pass: contiguous, coalesced, served by L2 / the Infinity Cache.  Inside a pass the points keep
-//      their neighbours (wave, lane order), so the result stores of a wave fall into a few lines;
+//      consecutive spans whose rows fit the LDS slab) - wave ballots, no atomics; the order (batch position | span of
+//      every point, 4 bytes) goes to a chunk-private scratch in global memory, which the same workgroup reads back
+//      pass by pass; the points themselves are read again from the caller's arrays (L2 / Infinity Cache).  Inside
+//      a pass the points keep their neighbours (wave, lane order), so the reads and the result stores of a wave fall
+//      into a few lines;
 //   2. for every pass: stages the slab (rows [g spp, g spp + spp + order0 - 1) of the table: one contiguous copy) and
 //      the slice of the first variable's axis table the pass needs, then evaluates the pass's points with
 //      eval_gather's arithmetic (same basis functions, same window_contract: bitwise the same results);
@@ -164,12 +165,11 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
         const int cnt = (int)((N - lo) < SLAB_CHUNK ? (N - lo) : SLAB_CHUNK);
         __syncthreads();                                     // tables staged (first chunk); the previous chunk's last pass is done with LDS
         {   // ---- phase 1: order the chunk by pass
-            T pu[SLAB_PPT], pv[SLAB_PPT];
+            T pu[SLAB_PPT];
 #pragma unroll
             for (int k = 0; k < SLAB_PPT; ++k) {
                 const int i = k * SLAB_BLOCK + (int)threadIdx.x;
                 pu[k] = prm.p[0][lo + (i < cnt ? i : cnt - 1)];
-                pv[k] = prm.p[1][lo + (i < cnt ? i : cnt - 1)];
             }
             int ix0[SLAB_PPT], ps[SLAB_PPT];
 #pragma unroll
@@ -215,11 +215,6 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
                 if (ps[k] >= 0) {
                     const unsigned p = wcnt[wave * SLAB_MAX_PASS + ps[k]] + rank[k];
                     const int i = k * SLAB_BLOCK + (int)threadIdx.x;
-                    SlabPt<T> q;
-                    q.u = pu[k];
-                    q.v = pv[k];
-                    if ((q.v < d.lo[1]) | (q.v > d.hi[1])) record_bad(bad, base + lo + i);
-                    spts[lo + p] = q;
                     sidx[lo + p] = (unsigned)i | ((unsigned)ix0[k] << 16);
                 }
             }
@@ -253,16 +248,29 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
             const unsigned tab0_a = (unsigned)(size_t)stab0 - (unsigned)(r0 * (int)sizeof(T)), tab1_a = (unsigned)(size_t)stab1;
             // (register-tight instantiations - fp64 from order 5 on - read each point when they get to it)
             constexpr bool BOTH = 2 * ((O - 1) + O * (O - 1) / 2) * ((int)sizeof(T) / 4) <= 40;
+            // The point itself is read again from the caller's arrays at its batch position: the chunk's lines were
+            // loaded by this CU a moment ago (L2 / Infinity Cache), and neighbours in a pass are near neighbours in
+            // the batch - a scratch copy of {u, v} in pass order cost 160 MB of writes and reads per 10 M points more.
+            // Two dependent loads per point (order entry, then the point): the entry is requested two iterations ahead,
+            // the point one iteration ahead.
             int p = p0 + (int)threadIdx.x;
             SlabPt<T> qn;
-            unsigned en = 0;
-            if (BOTH && p < p1) { qn = spts[lo + p]; en = sidx[lo + p]; }
+            unsigned en = 0, en2 = 0;
+            auto fetch_pt = [&]() {
+                qn.u = prm.p[0][lo + (en & 0xffffu)];
+                qn.v = prm.p[1][lo + (en & 0xffffu)];
+            };
+            if (p < p1) { en = sidx[lo + p]; if (BOTH) fetch_pt(); }
+            if (p + SLAB_BLOCK < p1) en2 = sidx[lo + p + SLAB_BLOCK];
             if (dbg & 1) p = p1;
             for (; p < p1; p += SLAB_BLOCK) {
-                if (!BOTH) { qn = spts[lo + p]; en = sidx[lo + p]; }
+                if (!BOTH) fetch_pt();
                 const SlabPt<T> q = qn;
                 const unsigned e = en;
-                if (BOTH && p + SLAB_BLOCK < p1) { qn = spts[lo + p + SLAB_BLOCK]; en = sidx[lo + p + SLAB_BLOCK]; }     // the next point streams in meanwhile
+                en = en2;
+                if (p + 2 * SLAB_BLOCK < p1) en2 = sidx[lo + p + 2 * SLAB_BLOCK];
+                if (BOTH && p + SLAB_BLOCK < p1) fetch_pt();                // the next point streams in meanwhile
+                if ((q.v < d.lo[1]) | (q.v > d.hi[1])) record_bad(bad, base + lo + (long long)(e & 0xffffu));
                 const int i0 = (int)(e >> 16);
                 const int i1 = find_span_lut<T>(stab1, slut, td, 1, d.lo[1], d.ncoef[1], q.v);
                 T b[2][O];
