@@ -1124,6 +1124,11 @@ static bsk_status dispatch_jac(bsk_spline s, const Params<T> &prm, long long n, 
 #undef JMIX
         }
     }
+    // large batches on L2-resident tables of three variables: the fused jacobian of the cell-order pipeline
+    if (s->nInd == 3 && has_fixed_path(s) && s->coef_aos && s->variant != 1) {
+        const bsk_status r = cellsort_jacobian_any<T>(s, prm, n, out, st);
+        if (r != BSK_ERR_UNSUPPORTED) return r;
+    }
     // otherwise nInd unit-derivative passes, as the reference does (_spline_evaluation.py:205-213), each on the
     // best evaluation kernel for the shape (mixed orders: eval_mixed / gather; else eval_generic)
     for (int j = 0; j < s->nInd; ++j) {

@@ -1206,14 +1206,14 @@ __device__ __forceinline__ void cs_wait_row(CsRow<O> &row)
     else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(row.r[0]), "+v"(row.r[1]), "+v"(row.r[2]) : "n"(CNT) : "memory");
 }
 
-template <int O, int ND, int ROW>
+template <int O, int ND, int ROW, int AHEAD>
 __device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O], float wgt,
-                                        CsRow<O> (&buf)[CS_AHEAD + 1], cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1],
+                                        CsRow<O> (&buf)[AHEAD + 1], cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1],
                                         cs_f4 (&accr)[(O % 4) > 0 ? (O % 4) : 1])
 {
-    constexpr int ROWS = O * O, G = O / 4, R = O % 4, NS = CS_AHEAD + 1;
+    constexpr int ROWS = O * O, G = O / 4, R = O % 4, NS = AHEAD + 1;
     if constexpr (ROW < ROWS) {
-        if constexpr (ROW + CS_AHEAD < ROWS) cs_issue_row<O, ROW + CS_AHEAD>(a_addr, r_addr, buf[(ROW + CS_AHEAD) % NS]);
+        if constexpr (ROW + AHEAD < ROWS) cs_issue_row<O, ROW + AHEAD>(a_addr, r_addr, buf[(ROW + AHEAD) % NS]);
         // the next row's weight is formed a row early (pinned above this row's wait): a product right in front of the
         // MFMA that reads it costs wait states
         float wnext = 0.f;
@@ -1221,7 +1221,7 @@ __device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const 
             wnext = b0[(ROW + 1) / O] * b1[(ROW + 1) % O];
             asm volatile("" : "+v"(wnext) :: "memory");
         }
-        constexpr int later = ROWS - 1 - ROW < CS_AHEAD ? ROWS - 1 - ROW : CS_AHEAD;
+        constexpr int later = ROWS - 1 - ROW < AHEAD ? ROWS - 1 - ROW : AHEAD;
         CsRow<O> &row = buf[ROW % NS];
         cs_wait_row<O, (G + R) * later>(row);
         if constexpr (G >= 1) {
@@ -1230,31 +1230,36 @@ __device__ __forceinline__ void cs_rows(unsigned a_addr, unsigned r_addr, const 
         }
 #pragma unroll
         for (int r2 = 0; r2 < R; ++r2) accr[r2] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.r[r2], wgt, accr[r2], 0, 0, 0);
-        cs_rows<O, ND, ROW + 1>(a_addr, r_addr, b0, b1, wnext, buf, accg, accr);
+        cs_rows<O, ND, ROW + 1, AHEAD>(a_addr, r_addr, b0, b1, wnext, buf, accg, accr);
     }
 }
 
-template <int O, int ND>
+template <int O, int ND, int AHEAD = CS_AHEAD>
 __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&b1)[O],
                                             cs_f4 (&accg)[(O / 4) > 0 ? (O / 4) * ND : 1], cs_f4 (&accr)[(O % 4) > 0 ? (O % 4) : 1])
 {
-    CsRow<O> buf[CS_AHEAD + 1];
+    CsRow<O> buf[AHEAD + 1];
     constexpr int ROWS = O * O;
-    if constexpr (ROWS > 0 && CS_AHEAD > 0) cs_issue_row<O, 0>(a_addr, r_addr, buf[0]);
-    if constexpr (ROWS > 1 && CS_AHEAD > 1) cs_issue_row<O, 1>(a_addr, r_addr, buf[1]);
-    if constexpr (ROWS > 2 && CS_AHEAD > 2) cs_issue_row<O, 2>(a_addr, r_addr, buf[2]);
-    if constexpr (ROWS > 3 && CS_AHEAD > 3) cs_issue_row<O, 3>(a_addr, r_addr, buf[3]);
-    static_assert(CS_AHEAD <= 4, "prologue");
-    cs_rows<O, ND, 0>(a_addr, r_addr, b0, b1, b0[0] * b1[0], buf, accg, accr);
+    if constexpr (ROWS > 0 && AHEAD > 0) cs_issue_row<O, 0>(a_addr, r_addr, buf[0]);
+    if constexpr (ROWS > 1 && AHEAD > 1) cs_issue_row<O, 1>(a_addr, r_addr, buf[1]);
+    if constexpr (ROWS > 2 && AHEAD > 2) cs_issue_row<O, 2>(a_addr, r_addr, buf[2]);
+    if constexpr (ROWS > 3 && AHEAD > 3) cs_issue_row<O, 3>(a_addr, r_addr, buf[3]);
+    static_assert(AHEAD <= 4, "prologue");
+    cs_rows<O, ND, 0, AHEAD>(a_addr, r_addr, b0, b1, b0[0] * b1[0], buf, accg, accr);
 }
 
-template <typename T, int O, int ND, bool MFMA, bool DERIV = true>
+// JAC: the fused jacobian - the evaluation body runs three times over the same sorted tile, once per unit derivative
+// request, and stores the partials of a record at tmp[j * N + dest]: one tile sort, one set of record reads and bundle
+// stagings instead of three.  (Sharing the value bases between the passes - six recursions instead of nine - needs five to
+// fifteen registers more than four waves per SIMD leave: measured 32 - 46 spilled registers in three arrangements.)
+template <typename T, int O, int ND, bool MFMA, bool DERIV = true, bool JAC = false>
 __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
                                                      BinOut<T, ND> *__restrict__ tmp, const Wrt wrt, const int dest_bits)
 {
     static_assert(!MFMA || (sizeof(T) == 4 && ND <= 4), "the 4x4x1 fp32 MFMA form");
+    static_assert(!JAC || DERIV, "the fused jacobian requests derivatives");
     static_assert(sizeof(BinRec<T, 3>) == 4 * sizeof(T), "record = u, v, w, tag");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ncl = d.ncoef[2];
@@ -1402,13 +1407,17 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                 const unsigned tag = word_tag<T>(r.v[3]);
                 const int ix2 = min((int)(tag >> dest_bits), S2 - 1);
                 const unsigned dest = tag & dest_mask;
+                // JAC: the body below once per variable j with the unit derivative request e_j (a real loop: the sorted tile,
+                // the record and the scalar span tables are shared; registers as in the derivative kernel)
+                auto body = [&](const int j) __attribute__((always_inline)) {
+                const int w0 = JAC ? (int)(j == 0) : wrt.w[0], w1 = JAC ? (int)(j == 1) : wrt.w[1], w2 = JAC ? (int)(j == 2) : wrt.w[2];
                 T b[3][O];
                 SpanTab<T, O> st2;
                 span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
-                basis_regs<T, O, DERIV>(st0, r.v[0], wrt.w[0], b[0]);
-                basis_regs<T, O, DERIV>(st1, r.v[1], wrt.w[1], b[1]);
+                basis_regs<T, O, DERIV>(st0, r.v[0], w0, b[0]);
+                basis_regs<T, O, DERIV>(st1, r.v[1], w1, b[1]);
                 span_tab_wait<T, O>(st2);
-                basis_regs<T, O, DERIV>(st2, r.v[2], wrt.w[2], b[2]);
+                basis_regs<T, O, DERIV>(st2, r.v[2], w2, b[2]);
                 T res[ND];
                 if constexpr (MFMA) {
                     // The steps m of the THIRD variable go four at a time into the ROWS of the outer product:
@@ -1429,7 +1438,9 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     for (int q2 = 0; q2 < R; ++q2) accr[q2] = cs_f4{0.f, 0.f, 0.f, 0.f};
                     const unsigned a_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + (lane & 3)) * (ROWS * 16));
                     const unsigned r_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + 4 * G) * (ROWS * 16) + (lane & 3) * 4);
-                    cs_contract<O, ND>(a_addr, r_addr, b[0], b[1], accg, accr);
+                    // (JAC: reads one row ahead instead of four - the record and its addresses live across the three
+                    // passes and need the registers; the depth measured no different on the value kernel)
+                    cs_contract<O, ND, JAC ? 1 : CS_AHEAD>(a_addr, r_addr, b[0], b[1], accg, accr);
 #pragma unroll
                     for (int dd = 0; dd < ND; ++dd) {
                         T sum = T(0);
@@ -1449,7 +1460,14 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     BinOut<T, ND> o;
 #pragma unroll
                     for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);
-                    tmp[dest] = o;            // chunk order (bin_unpermute_stream); (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
+                    tmp[(JAC ? (long long)j * N : 0ll) + dest] = o;   // chunk order (bin_unpermute_stream); (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
+                }
+                };
+                if constexpr (JAC) {
+#pragma unroll 1
+                    for (int j = 0; j < 3; ++j) body(j);
+                } else {
+                    body(0);                                     // (no loop around the plain kernels: a one-trip loop kept by the pragma cost them 10 %)
                 }
             }
             asm volatile("" :: "v"(touch));

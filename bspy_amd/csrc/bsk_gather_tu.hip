@@ -48,8 +48,11 @@ constexpr long long BIN_MIN_POINTS = 1 << 18;
 // launch takes at most 2^26 - 1 points (span keys < 64) or 2^24 - 1 (< 256): larger batches run piece by piece.
 template <typename T, int O>
 static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Params<T> &prm, long long n, T *out, long long ostride,
-                                           const Wrt &w, hipStream_t st, size_t cs_lds_mfma, size_t cs_lds_valu)
+                                           const Wrt &w, hipStream_t st, size_t cs_lds_mfma, size_t cs_lds_valu, bool jac = false)
 {
+    // jac: the fused jacobian (eval_cellsort<..., JAC>): three result arrays in the workspace, three streaming un-permutes
+    // into out[(dep * 3 + j) * n + i] (the caller passes ostride = 3 n); MFMA form only
+    if (jac && (sizeof(T) != 4 || s->variant == 12)) return BSK_ERR_UNSUPPORTED;
     const Desc<T> &d = desc_of<T>(s);
     const TileDesc<T> &td = tile_of<T>(s);
     const int S2 = s->ncoef[2] - s->order[2] + 1;
@@ -74,7 +77,7 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
 
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_lpos = 0, o_rec = o_lpos + up(2 * (size_t)piece), o_tmp = o_rec + up(sizeof(BinRec<T, 3>) * (size_t)piece);
-    const size_t o_tot = o_tmp + up(out_sz * (size_t)piece), o_start = o_tot + up(4 * (size_t)(bp.cells + 1));
+    const size_t o_tot = o_tmp + up(out_sz * (size_t)piece * (jac ? 3 : 1)), o_start = o_tot + up(4 * (size_t)(bp.cells + 1));
     const size_t o_rows = o_start + up(4 * (size_t)bp.cells), total = o_rows + up(4 * (size_t)bp.cells * s->num_cu);
     HIPCHK(s->bin_ws.reserve(total));
     char *ws = static_cast<char *>(s->bin_ws.p);
@@ -94,7 +97,8 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     for (int iv = 0; iv < 3; ++iv) deriv |= w.w[iv] != 0;
     constexpr bool MF = sizeof(T) == 4;
     const bool mfma = MF && s->variant != 12;
-    s->last_kernel = mfma ? "cell-order pipeline (eval_cellsort, MFMA)" : "cell-order pipeline (eval_cellsort, VALU)";
+    s->last_kernel = jac ? "cell-order pipeline (eval_cellsort, MFMA, fused jacobian)"
+                         : mfma ? "cell-order pipeline (eval_cellsort, MFMA)" : "cell-order pipeline (eval_cellsort, VALU)";
 
     for (long long off = 0; off < n; off += piece) {
         const long long np = std::min(piece, n - off);
@@ -121,7 +125,13 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
 #define CS_ND(ND)                                                                                                        \
     case ND: {                                                                                                           \
         BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
-        if (mfma) {                                                                                                      \
+        if constexpr (MF) if (jac) {                                                                                     \
+            HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true, MF>, cs_lds_mfma));                                       \
+            hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true, MF>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,  \
+                               bp, tab, aos, start, rec, np, tmp, w, dest_bits);                                         \
+        }                                                                                                                \
+        if (jac) {                                                                                                       \
+        } else if (mfma) {                                                                                               \
             if (deriv) {                                                                                                 \
                 HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true>, cs_lds_mfma));                                       \
                 hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d, \
@@ -139,7 +149,9 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
         stage_mark(s, st, "eval_cellsort");                                                                              \
         const size_t lds_u = (size_t)bp.chunk * sizeof(BinOut<T, ND>);                                                   \
         HIPCHK(allow_lds(bin_unpermute_stream<T, ND>, lds_u));                                                           \
-        hipLaunchKernelGGL((bin_unpermute_stream<T, ND>), dim3(pgrid), dim3(1024), lds_u, st, bp, np, lpos, tmp, out + off, ostride); \
+        for (int j = 0; j < (jac ? 3 : 1); ++j)                                                                          \
+            hipLaunchKernelGGL((bin_unpermute_stream<T, ND>), dim3(pgrid), dim3(1024), lds_u, st, bp, np, lpos, tmp + (size_t)j * np, \
+                               out + (long long)j * n + off, ostride);                                                   \
         stage_mark(s, st, "bin_unpermute_stream");                                                                       \
     } break;
         switch (s->nDep) {
@@ -154,7 +166,7 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
 
 template <typename T, int NIND, int O, bool MIXED>
 static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
-                                     const Wrt &w, hipStream_t st)
+                                     const Wrt &w, hipStream_t st, bool jac = false)
 {
     if constexpr (NIND < 2) {
         return BSK_ERR_UNSUPPORTED;
@@ -241,11 +253,12 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
             cellsort = bp.sh0 == 0 && bp.sh1 == 0 && S2 <= CS_MAX_S2 && s->variant != 13 && s->variant != 14 &&
                        std::max(cs_lds_mfma, cs_lds_valu) <= s->lds_max / 2;
             if (cellsort) {
-                const bsk_status r = launch_cellsort_pipeline<T, O>(s, bp, prm, n, out, ostride, w, st, cs_lds_mfma, cs_lds_valu);
+                const bsk_status r = launch_cellsort_pipeline<T, O>(s, bp, prm, n, out, ostride, w, st, cs_lds_mfma, cs_lds_valu, jac);
                 if (r != BSK_ERR_UNSUPPORTED) return r;
                 cellsort = false;                                 // falls back to the round-2 sort + eval_binned_lds
             }
         }
+        if (jac) return BSK_ERR_UNSUPPORTED;                      // the fused jacobian exists on the eval_cellsort pipeline only
 #define BINNED_ND(ND)                                                                                                    \
     case ND: {                                                                                                           \
         layout(sizeof(BinOut<T, ND>));                                                                                   \
@@ -403,6 +416,25 @@ bsk_status gather_or_binned_any(bsk_spline s, bool mixed, const Params<T> &prm, 
 #undef GB_CASE
     return BSK_ERR_UNSUPPORTED;
 }
+
+// Fused jacobian of a large batch on an L2-resident table (three variables of one order, fp32: the eval_cellsort
+// pipeline).  out[(dep * 3 + j) * n + i].  BSK_ERR_UNSUPPORTED when the shape is not covered: the caller then runs
+// nInd derivative passes (which share one sort of the batch).
+template <typename T>
+bsk_status cellsort_jacobian_any(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st)
+{
+    if (s->nInd != 3 || !s->same_order || !s->coef_aos || s->order[0] < 1 || s->order[0] > 6) return BSK_ERR_UNSUPPORTED;
+    Wrt w;
+    for (int iv = 0; iv < MAXI; ++iv) w.w[iv] = 0;
+    switch (s->order[0]) {
+#define CJ_CASE(O) case O: return launch_eval_binned<T, 3, O, false>(s, prm, n, out, 3 * n, w, st, true);
+        CJ_CASE(1) CJ_CASE(2) CJ_CASE(3) CJ_CASE(4) CJ_CASE(5) CJ_CASE(6)
+#undef CJ_CASE
+        default: return BSK_ERR_UNSUPPORTED;
+    }
+}
+template bsk_status cellsort_jacobian_any<float>(bsk_spline, const Params<float> &, long long, float *, hipStream_t);
+template bsk_status cellsort_jacobian_any<double>(bsk_spline, const Params<double> &, long long, double *, hipStream_t);
 
 template bsk_status gather_or_binned_any<float>(bsk_spline, bool, const Params<float> &, long long, float *, long long,
                                                 const Wrt &, hipStream_t);

@@ -167,3 +167,8 @@ inline hipError_t allow_lds(K kernel, size_t bytes)
 template <typename T>
 bsk_status gather_or_binned_any(bsk_spline s, bool mixed, const Params<T> &prm, long long n, T *out, long long ostride,
                                 const Wrt &w, hipStream_t st);
+
+// Fused jacobian of large batches on L2-resident tables (bsk_gather_tu.hip, eval_cellsort<..., JAC>);
+// BSK_ERR_UNSUPPORTED when the shape is not covered.
+template <typename T>
+bsk_status cellsort_jacobian_any(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st);

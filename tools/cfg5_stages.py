@@ -1,6 +1,6 @@
 """cfg5 (trivariate order 5, 40^3 x 4 fp32): per-kernel times of the cell-order pipeline from HIP events between its
 kernels (bsk_debug_stage_times, the BSK_INTERNAL measurement hook), and the whole call.
-usage: python tools/cfg5_stages.py [points] [reps]"""
+usage: python tools/cfg5_stages.py [points] [reps] [--jac]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -26,13 +26,15 @@ def stage_times(tables, fn, reps=10):
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    jac = "--jac" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(args[0]) if len(args) > 0 else 10_000_000
+    reps = int(args[1]) if len(args) > 1 else 20
     nind, ndep, order, ncoef, knots, coefs, dt = cases.bench_spline(5)
     t = bspy_amd.DeviceSpline(order, ncoef, knots, coefs, dt)
     p = [torch.rand(n, dtype=torch.float32, device="cuda") for _ in range(3)]
-    o = torch.empty((4, n), dtype=torch.float32, device="cuda")
-    f = lambda: t.evaluate_device(p, out=o, check=False)
+    o = torch.empty((4, 3, n) if jac else (4, n), dtype=torch.float32, device="cuda")
+    f = (lambda: t.jacobian_device(p, out=o, check=False)) if jac else (lambda: t.evaluate_device(p, out=o, check=False))
     for _ in range(30): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
