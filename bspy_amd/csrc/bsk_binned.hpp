@@ -23,6 +23,11 @@
 // No global atomics (64 lanes adding to 64 different addresses run at 0.08 TB/s on MI355X); a
 // point's result does not depend on its slot, so the non-deterministic order inside a cell (LDS
 // atomics of different waves) cannot change the output.
+//
+// The kernels above are the ROUND-2 sort: they serve eval_binned_lds (two-variable tables too large to be
+// streamed through LDS, mixed orders of three variables, tables beyond the span-key range).  Three variables of
+// one order - the cfg5 shape - take the round-3 sort further down (bin_totals / bin_starts / bin_scatter_tag /
+// bin_unpermute_stream) in front of eval_cellsort.
 #pragma once
 #include "bsk_gather.hpp"
 #include <type_traits>
@@ -72,21 +77,6 @@ __device__ __forceinline__ int bin_cell(const T *stab, const unsigned *slut, con
     const int i0 = find_span_lut<T>(stab + d.off[0], slut, td, 0, d.lo[0], d.ncoef[0], u0) - d.order[0];
     const int i1 = find_span_lut<T>(stab + d.off[1], slut, td, 1, d.lo[1], d.ncoef[1], u1) - d.order[1];
     return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
-}
-
-// Span of the third variable (the key of eval_cellsort's second grouping), found by the scatter kernels - they
-// wait for HBM and have the issue slots - through the bucket table and the knots in global memory (two dependent
-// L1 hits), and carried in the record's spare word.  (In bin_count the same search cost 23 us, in eval_cellsort
-// the bisection was ~85 of its ~360 vector instructions per point.)
-template <typename T, int NIND, typename KP, typename LP>
-__device__ __forceinline__ void rec_key(BinRec<T, NIND> &r, const Desc<T> &d, const TileDesc<T> &td, KP knots2, LP lut)
-{
-    // knots2: knots of the third variable; lut: bucket tables, indexed from td.lut_off[2]
-    if constexpr (NIND == 3) {
-        using Tag = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
-        const int key = find_span_lut<T>(knots2, lut, td, 2, d.lo[2], d.ncoef[2], r.v[2]) - d.order[2];
-        r.v[3] = __builtin_bit_cast(T, (Tag)(unsigned)key);
-    }
 }
 
 // LDS: [axis tables][cells x u32]
@@ -146,7 +136,7 @@ __global__ __launch_bounds__(1024) void bin_count(const Desc<T> d, const TileDes
 //   bin_scan_ranges  thread = bin, workgroup = 256 bins x one range of chunks: exclusive prefix inside the range
 //                    (in place), range total -> Tr[range][bin]; rows are read and written coalesced, sixteen in flight
 //   bin_scan_top     the ranges, then the bins (one workgroup)
-__global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigned *__restrict__ M, unsigned *__restrict__ Tr)
+static __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigned *__restrict__ M, unsigned *__restrict__ Tr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (i >= bp.cells) return;
@@ -166,7 +156,7 @@ __global__ __launch_bounds__(256) void bin_scan_ranges(const BinPlan bp, unsigne
 
 // one workgroup, thread = BIN_MAX_CELLS / 1024 consecutive bins: exclusive prefix over the ranges (in place), bin
 // totals, and their exclusive prefix over the bins -> start[]
-__global__ __launch_bounds__(1024) void bin_scan_top(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ start)
+static __global__ __launch_bounds__(1024) void bin_scan_top(const BinPlan bp, unsigned *__restrict__ Tr, unsigned *__restrict__ start)
 {
     __shared__ unsigned s[16];
     constexpr int PER = BIN_MAX_CELLS / 1024;
@@ -219,7 +209,7 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
                                                          const unsigned *__restrict__ start,
                                                          BinRec<T, NIND> *__restrict__ rec, unsigned *__restrict__ slot,
                                                          const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
-                                                         const unsigned *__restrict__ glut, const int keyed,
+                                                         const unsigned *__restrict__ glut,
                                                          unsigned long long *bad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -239,10 +229,6 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
             for (int q = 0; q < BinRec<T, NIND>::WORDS; ++q) r[k].v[q] = T(0);
 #pragma unroll
             for (int iv = 0; iv < NIND; ++iv) r[k].v[iv] = prm.p[iv][nn];
-        }
-        if (keyed) {
-#pragma unroll
-            for (int k = 0; k < BIN_ILP; ++k) rec_key<T, NIND>(r[k], d, td, gtab + d.off[2], glut);
         }
 #pragma unroll
         for (int k = 0; k < BIN_ILP; ++k) {
@@ -284,7 +270,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                                                        BinRec<T, NIND> *__restrict__ rec, unsigned short *__restrict__ lpos,
                                                        unsigned short *__restrict__ pbin, unsigned *__restrict__ Lb,
                                                        const Desc<T> d, const TileDesc<T> td, const T *__restrict__ gtab,
-                                                       const unsigned *__restrict__ glut, const int keyed,
+                                                       const unsigned *__restrict__ glut,
                                                        unsigned long long *bad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -295,14 +281,6 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
     BinRec<T, NIND> *srec = reinterpret_cast<BinRec<T, NIND> *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15));
     unsigned short *sbin = reinterpret_cast<unsigned short *>(srec + bp.chunk);
     __shared__ unsigned s_wave[16];
-    // keyed == 2: the knots and bucket table of the third variable behind the chunk (two LDS reads per key instead of
-    // two L1 hits)
-    T *skn2 = reinterpret_cast<T *>(smem + ((12 * (size_t)cells + 15) & ~(size_t)15) + (((size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2) + 15) & ~(size_t)15));
-    unsigned *slut2 = reinterpret_cast<unsigned *>(skn2 + ((d.nk[NIND == 3 ? 2 : 0] + 3) & ~3));
-    if (keyed == 2) {
-        for (int i = threadIdx.x; i < d.nk[2]; i += blockDim.x) skn2[i] = gtab[d.off[2] + i];
-        for (int i = threadIdx.x; i < td.lut_m[2]; i += blockDim.x) slut2[i] = glut[td.lut_off[2] + i];
-    }
     // PERSISTENT: one workgroup per CU (the chunk fills LDS) walks the chunks blockIdx, blockIdx + grid, ...  The next
     // chunk's points, bins and run starts are fetched into registers BEFORE the store phase of the current one, so that
     // loads and stores of a CU overlap (one chunk per workgroup: load, order, store one after the other, 125 us).
@@ -346,13 +324,6 @@ __global__ __launch_bounds__(1024) void bin_scatter_wc(const BinPlan bp, const P
                 if constexpr (NIND == 3) { if ((r[k].v[2] < d.lo[2]) | (r[k].v[2] > d.hi[2])) record_bad(bad, lo + k * 1024 + (long long)threadIdx.x); }
                 rk[k] = atomicAdd(&lcnt[ck[k]], 1u);
             }
-        if (keyed == 2) {                                         // span tables of the third variable in LDS
-#pragma unroll
-            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, skn2, slut2 - td.lut_off[NIND == 3 ? 2 : 0]);
-        } else if (keyed) {
-#pragma unroll
-            for (int k = 0; k < WC_PPT; ++k) rec_key<T, NIND>(r[k], d, td, gtab + d.off[NIND == 3 ? 2 : 0], glut);
-        }
         __syncthreads();
         {   // exclusive scan of the bin counts: every thread NEXT_PPT consecutive bins, wave scans, 16 wave totals
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -635,7 +606,7 @@ __global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDe
 // workgroup w's records of bin b is start[b] + rows[w][b].
 // Workgroup = 64 bins x 16 groups of rows (1024 lanes): a lane scans its group's rows (16 in flight), the 16 groups of
 // a bin are combined through LDS.
-__global__ __launch_bounds__(1024) void bin_starts(const int cells, const int G, unsigned *__restrict__ rows, unsigned *__restrict__ tot,
+static __global__ __launch_bounds__(1024) void bin_starts(const int cells, const int G, unsigned *__restrict__ rows, unsigned *__restrict__ tot,
                                                     unsigned *__restrict__ start, unsigned *__restrict__ done)
 {
     __shared__ unsigned part[16][65];

@@ -5,7 +5,6 @@
 #include "bsk_tile.hpp"
 #include "bsk_gather.hpp"
 #include "bsk_binned.hpp"
-#include "bsk_slab.hpp"
 
 template <typename T, int NIND, int O, bool MIXED>
 static bsk_status launch_eval_gather(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
@@ -282,13 +281,12 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
         hipLaunchKernelGGL(bin_scan_top, dim3(1), dim3(1024), 0, st, bp, Tr, start);                                     \
         if (wc) {                                                                                                        \
             size_t lds_s = ((12 * (size_t)bp.cells + 15) & ~(size_t)15) + (size_t)bp.chunk * (sizeof(BinRec<T, NIND>) + 2); \
-            const int keyed = 0;         /* (round 2 keyed the records for eval_cellsort here; bin_scatter_tag does now) */ \
             HIPCHK(allow_lds(bin_scatter_wc<T, NIND>, lds_s));                                                           \
             hipLaunchKernelGGL((bin_scatter_wc<T, NIND>), dim3(std::min(bp.chunks, s->num_cu)), dim3(1024), lds_s, st, bp, prm, n, cell, M,   \
-                               Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, keyed, s->bad);                        \
+                               Tr, start, rec, reinterpret_cast<unsigned short *>(slot), pbin, Lb, d, td, tab, s->lut, s->bad);                        \
         } else                                                                                                           \
         hipLaunchKernelGGL((bin_scatter<T, NIND>), dim3(bp.chunks), dim3(bin_block), sizeof(unsigned) * (size_t)bp.cells, \
-                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, 0, s->bad);             \
+                           st, bp, prm, n, cell, M, Tr, start, rec, slot, d, td, tab, s->lut, s->bad);             \
         }                                                                                                                \
         HIPCHK(allow_lds(eval_binned_lds<T, NIND, O, ND, MIXED>, tab_b + bundle_b));                                     \
         hipLaunchKernelGGL((eval_binned_lds<T, NIND, O, ND, MIXED>), dim3(egrid), dim3(256), tab_b + bundle_b, st, d,    \
@@ -311,84 +309,14 @@ static bsk_status launch_eval_binned(bsk_spline s, const Params<T> &prm, long lo
     }
 }
 
-// Surfaces whose table can be streamed through LDS once per chunk of 4096 points (bsk_slab.hpp): no global sort.
-constexpr long long SLAB_MIN_POINTS = 1 << 16;
-
-template <typename T, int O, bool MIXED>
-static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride, const Wrt &w,
-                                    hipStream_t st)
-{
-    if (s->nInd != 2 || s->nDep > 4 || !s->coef_aos || n < SLAB_MIN_POINTS) return BSK_ERR_UNSUPPORTED;
-    if (s->variant == 7 || s->variant == 13 || s->variant == 14) return BSK_ERR_UNSUPPORTED;     // pinned to the other large-table paths
-    const Desc<T> &d = desc_of<T>(s);
-    const TileDesc<T> &td = tile_of<T>(s);
-    if ((size_t)d.coef_len * sizeof(T) > SLAB_MAX_TABLE || s->ncoef[0] > 65535) return BSK_ERR_UNSUPPORTED;
-    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    SlabPlan sp;
-    size_t off = up16(sizeof(T) * (size_t)d.nk[1] * s->order[1]);
-    sp.off_lut = (unsigned)off;
-    off += up16(4 * (size_t)td.lut_len);
-    sp.off_wcnt = (unsigned)off;
-    off += up16(4 * (size_t)SLAB_WAVES * SLAB_MAX_PASS);
-    sp.off_pstart = (unsigned)off;
-    off += up16(4 * (size_t)(SLAB_MAX_PASS + 1));
-    sp.off_tab0 = (unsigned)off;
-    const size_t lds_wg = s->lds_max;                             // one workgroup per CU
-    if (off + 4096 > lds_wg) return BSK_ERR_UNSUPPORTED;
-    // a pass of spp spans needs (spp + order0 - 1) table rows and order0 x (spp + order0) axis-table entries
-    const size_t rowbytes = (size_t)s->ncoef[1] * s->nDep * sizeof(T), slicebytes = (size_t)s->order[0] * sizeof(T);
-    const int S0 = s->ncoef[0] - s->order[0] + 1;
-    const long long room = (long long)lds_wg - (long long)off - 256 - (long long)(s->order[0] - 1) * (long long)rowbytes -
-                           (long long)s->order[0] * (long long)slicebytes;
-    int spp = (int)std::min<long long>(room / (long long)(rowbytes + slicebytes), S0);
-    if (spp < 1) return BSK_ERR_UNSUPPORTED;
-    sp.npass = (S0 + spp - 1) / spp;
-    if (sp.npass > SLAB_MAX_PASS) return BSK_ERR_UNSUPPORTED;
-    spp = (S0 + sp.npass - 1) / sp.npass;                         // even passes
-    sp.spp = spp;
-    sp.rows = spp + s->order[0] - 1;
-    sp.snk = spp + s->order[0];
-    sp.off_slab = (unsigned)(off + up16((size_t)sp.snk * slicebytes));
-    sp.total = (unsigned)(sp.off_slab + up16((size_t)sp.rows * rowbytes));
-    if (sp.total > lds_wg) return BSK_ERR_UNSUPPORTED;
-    // chunk-private scratch of the order: batch position | span of every point
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return BSK_ERR_UNSUPPORTED;                               // the workspace may have to be (re)allocated
-    }
-    HIPCHK(s->bin_ws.reserve(4 * (size_t)n + 256));
-    SlabPt<T> *spts = nullptr;                                    // (the points are read again from the caller's arrays)
-    unsigned *sidx = reinterpret_cast<unsigned *>(s->bin_ws.p);
-    const long long nchunks = (n + SLAB_CHUNK - 1) / SLAB_CHUNK;
-    const int grid = (int)std::min<long long>(nchunks, (long long)s->num_cu);
-    static const int slab_dbg = getenv("BSK_SLAB_DBG") ? atoi(getenv("BSK_SLAB_DBG")) : 0;     // timing-only switches (tools/)
-    const T *tab = static_cast<const T *>(s->tab);
-    const T *aos = static_cast<const T *>(s->coef_aos);
-#define SLAB_ND(ND)                                                                                               \
-    case ND:                                                                                                      \
-        HIPCHK(allow_lds(eval_slab2<T, O, ND, MIXED>, sp.total));                                                 \
-        hipLaunchKernelGGL((eval_slab2<T, O, ND, MIXED>), dim3(grid), dim3(SLAB_BLOCK), sp.total, st, d, td, sp, tab, s->lut, aos, prm, n, \
-                           0ll, spts, sidx, out, ostride, w, s->bad, slab_dbg);                                   \
-        break;
-    switch (s->nDep) {
-        SLAB_ND(1) SLAB_ND(2) SLAB_ND(3) SLAB_ND(4)
-        default: return BSK_ERR_UNSUPPORTED;
-    }
-#undef SLAB_ND
-    s->last_kernel = "eval_slab2";
-    HIPCHK(hipGetLastError());
-    return BSK_OK;
-}
-
 // MIXED: variables of different orders (O = the largest); chosen by the call site so that every
 // (NIND, O) instantiates one form only
 template <typename T, int NIND, int O, bool MIXED>
 static bsk_status gather_or_binned(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride,
                                    const Wrt &w, hipStream_t st)
 {
-    if constexpr (NIND == 2) {
-        const bsk_status r2 = launch_eval_slab2<T, O, MIXED>(s, prm, n, out, ostride, w, st);
+    if constexpr (NIND == 2) {                                    // surfaces: table streamed through LDS (bsk_slab_tu.hip)
+        const bsk_status r2 = slab2_any<T>(s, MIXED, prm, n, out, ostride, w, st);
         if (r2 != BSK_ERR_UNSUPPORTED) return r2;
     }
     const bsk_status r = launch_eval_binned<T, NIND, O, MIXED>(s, prm, n, out, ostride, w, st);

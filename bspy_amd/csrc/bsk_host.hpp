@@ -172,3 +172,8 @@ bsk_status gather_or_binned_any(bsk_spline s, bool mixed, const Params<T> &prm, 
 // BSK_ERR_UNSUPPORTED when the shape is not covered.
 template <typename T>
 bsk_status cellsort_jacobian_any(bsk_spline s, const Params<T> &prm, long long n, T *out, hipStream_t st);
+
+// Surfaces whose table is streamed through LDS (bsk_slab_tu.hip, eval_slab2); BSK_ERR_UNSUPPORTED when not covered.
+template <typename T>
+bsk_status slab2_any(bsk_spline s, bool mixed, const Params<T> &prm, long long n, T *out, long long ostride, const Wrt &w,
+                     hipStream_t st);
