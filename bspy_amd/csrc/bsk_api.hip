@@ -5,6 +5,7 @@
 #include "bsk_stream.hpp"
 #include "bsk_rowrot.hpp"
 #include "bsk_uniform.hpp"
+#include "bsk_rec32.hpp"
 #include "bsk_host.hpp"
 
 #include <condition_variable>
@@ -850,6 +851,39 @@ static bsk_status launch_eval_lds(bsk_spline s, size_t lds, const Params<T> &prm
 #undef BSK_UNI_ND
 #undef BSK_UNI
                 return BSK_OK;
+            }
+            if constexpr (sizeof(T) == 4 && O == 4) {
+                // fp32 bicubics: everything in 16-byte LDS reads (bsk_rec32.hpp); BSK_VARIANT=9 keeps eval_rowrot
+                const size_t lds_r = r32_lds_bytes(s->ncoef[0] - 3, s->ncoef[1] - 3, td.lut_len, s->ncoef[0], s->ncoef[1]);
+                if (s->variant == 0 && s->nDep >= 1 && s->nDep <= 4 && lds_r + 256 <= s->lds_max) {
+                    const int per_cu_r = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_r));
+#define BSK_R32(DERIV_, ND_)                                                                                             \
+    do {                                                                                                                 \
+        HIPCHK(allow_lds(eval_rec32<DERIV_, ND_>, lds_r));                                                              \
+        hipLaunchKernelGGL((eval_rec32<DERIV_, ND_>), dim3(g), dim3(TILE), lds_r, st, d, td, tab, s->lut, coef, cp,     \
+                           (unsigned)m, n0, out + n0, ostride, w, s->bad);                                              \
+    } while (0)
+#define BSK_R32_ND(DERIV_)                                                                                               \
+    switch (s->nDep) {                                                                                                   \
+    case 1: BSK_R32(DERIV_, 1); break;                                                                                   \
+    case 2: BSK_R32(DERIV_, 2); break;                                                                                   \
+    case 3: BSK_R32(DERIV_, 3); break;                                                                                   \
+    default: BSK_R32(DERIV_, 4); break;                                                                                  \
+    }
+                    s->last_kernel = "eval_rec32";
+                    const long long cmaxr = rr_chunk_points();
+                    for (long long n0 = 0; n0 < n; n0 += cmaxr) {
+                        const long long m = std::min<long long>(n - n0, cmaxr);
+                        const int g = (int)std::max<long long>(1, std::min<long long>((m + TILE - 1) / TILE, (long long)s->num_cu * per_cu_r));
+                        Params<T> cp = prm;
+                        for (int iv = 0; iv < s->nInd; ++iv) cp.p[iv] = prm.p[iv] + n0;
+                        if (deriv) { BSK_R32_ND(true); } else { BSK_R32_ND(false); }
+                        HIPCHK(hipGetLastError());
+                    }
+#undef BSK_R32_ND
+#undef BSK_R32
+                    return BSK_OK;
+                }
             }
             const size_t lds_rr = rowrot_lds_bytes<T>(s);
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, s->lds_max / lds_rr));

@@ -18,7 +18,7 @@ import re
 import sys
 
 KERNELS = ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni",
-           "eval_cellsort", "eval_slab2")      # regular expressions on the mangled name
+           "eval_cellsort", "eval_slab2", "eval_rec32")      # regular expressions on the mangled name
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 WAIT = re.compile(r"lgkmcnt\((\d+)\)")
 

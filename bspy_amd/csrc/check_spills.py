@@ -10,7 +10,7 @@ for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)"
     name, scratch = m.group(1), int(m.group(2))
     if "eval_slab2IdLi6" in name:       # fp64, order 6: plain C++ instantiation, no asm LDS reads (bsk_slab.hpp)
         continue
-    if (any(k in name for k in ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni", "eval_slab2"))) and scratch:
+    if (any(k in name for k in ("eval_stream", "jac_stream", "eval_rowrot", "jac_rowrot", "curv_rowrot", "eval_uni", "jac_uni", "curv_uni", "eval_slab2", "eval_rec32"))) and scratch:
         bad.append((name, scratch))
 if bad:
     for name, scratch in bad:

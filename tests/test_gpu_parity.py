@@ -1103,6 +1103,59 @@ def test_cfg4_full_size(golden_tables):
     assert torch.equal(pos2, bspy_amd.tessellate_tables(tabs, (g, g), normals=False))
 
 
+@pytest.mark.parametrize("ncoef,ndep,knots_kind", [((64, 64), 3, "uniform"), ((4, 4), 3, "bezier"), ((9, 23), 1, "nonuniform"),
+                                                    ((37, 16), 4, "nonuniform"), ((12, 12), 2, "uniform")])
+def test_fp32_bicubic_records(ncoef, ndep, knots_kind):
+    """eval_rec32 (bsk_rec32.hpp): all-fp32 bicubics read per-span records and padded control points with 16-byte LDS
+    reads.  Every derivative multi-index up to total order 3, points on every knot and one ulp either side, odd batch
+    sizes, against the fp32 oracle and the general kernel (BSK_VARIANT=9 keeps eval_rowrot); out-of-domain index."""
+    rng = np.random.default_rng(hash((ncoef, ndep)) % 1000)
+    order = (4, 4)
+    if knots_kind == "uniform":
+        knots = [cases.clamped_uniform_knots(4, c, np.float32) for c in ncoef]
+    elif knots_kind == "bezier":
+        knots = [np.array((0, 0, 0, 0, 1, 1, 1, 1), np.float32)] * 2
+    else:
+        knots = [cases.nonuniform_knots(rng, 4, c, np.float32, -2.0, 3.0) for c in ncoef]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(np.float32)
+    t = DeviceSpline(order, ncoef, knots, coefs, np.float32)
+    os.environ["BSK_VARIANT"] = "9"
+    try:
+        general = DeviceSpline(order, ncoef, knots, coefs, np.float32)
+    finally:
+        del os.environ["BSK_VARIANT"]
+    for n in (1, 67, 20_011):
+        pts = []
+        for k, c in zip(knots, ncoef):
+            lo, hi = np.float32(k[3]), np.float32(k[c])
+            p = (lo + (hi - lo) * rng.random(n)).astype(np.float32)
+            d = np.unique(k)
+            e = np.concatenate((d, np.nextafter(d, np.float32(-np.inf)), np.nextafter(d, np.float32(np.inf)))).astype(np.float32)
+            e = e[(e >= lo) & (e <= hi)]
+            m = min(len(e), n)
+            p[:m] = rng.permutation(e)[:m]
+            pts.append(p)
+        for w in cases.all_wrt(2, 3) + [(4, 0), (0, 5)]:
+            out = t.evaluate(pts, list(w))
+            assert t.last_kernel() == "eval_rec32", t.last_kernel()
+            orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, list(w), pts)
+            assert bad == -1
+            observe("eval_rec32 vs fp32 oracle", np.abs(out - orc).max() / _scale(orc), 2e-5)
+            ref = general.evaluate(pts, list(w))
+            assert general.last_kernel() == "eval_rowrot"
+            observe("eval_rec32 vs eval_rowrot (fp32)", np.abs(out - ref).max() / _scale(ref), 2e-5)
+    bad = [p.copy() for p in pts]
+    bad[1][4_321] = np.nextafter(np.float32(knots[1][ncoef[1]]), np.float32(np.inf))
+    bad[0][9_999] = np.float32(-100.0)
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 4_321
+    nan = [p.copy() for p in pts]
+    nan[0][5] = np.nan
+    out = t.evaluate(nan)
+    assert np.isnan(out[:, 5]).all() and np.isfinite(out[:, 6]).all()
+
+
 def test_fused_curvature_orders_and_sizes():
     """curv_rowrot (fused Gaussian curvature on the LDS image) for both template orders against the
     oracle, on odd batch sizes; the piecewise bilinear case has S_uu = S_vv = 0."""
