@@ -210,6 +210,21 @@ def other_configs(torch, tables, u, v, n):
                           "stages: HIP events between the pipeline's kernels (bsk_debug_stage_times)"})
         res["cfg5_trivariate_f32"] = r
         t5.domain_status()
+        del p5, o5
+        # two shapes VERDICT r2 named (not BASELINE configs): the reference's examples/TomsNasty.json shape and an all-fp32 bicubic
+        rng = np.random.default_rng(3)
+        for key, order2, ncoef2, dt2, bpe in (("surface_o4x5_900x11_f64_TomsNasty_shape", (4, 5), (900, 11), np.float64, 40),
+                                              ("bicubic_64x64_f32", (4, 4), (64, 64), np.float32, 20)):
+            k2 = [cases.clamped_uniform_knots(o, c, dt2) for o, c in zip(order2, ncoef2)]
+            t2 = bspy_amd.DeviceSpline(order2, ncoef2, k2, rng.standard_normal((3, *ncoef2)).astype(dt2), dt2)
+            tdt2 = torch.float64 if dt2 == np.float64 else torch.float32
+            p2 = [torch.rand(n, dtype=tdt2, device=u.device) for _ in range(2)]
+            o2 = torch.empty((3, n), dtype=tdt2, device=u.device)
+            r = row(timed(torch, lambda: t2.evaluate_device(p2, out=o2, check=False), 10), n, bpe)
+            r["kernel"] = t2.last_kernel()
+            res[key] = r
+            t2.domain_status()
+            del p2, o2
     except Exception as e:  # diagnostic only: never fail the headline line
         res["error"] = repr(e)
     return res
