@@ -32,6 +32,7 @@ constexpr int SLAB_PPT = 8;                 // points per lane and chunk (the or
 constexpr int SLAB_CHUNK = SLAB_PPT * SLAB_BLOCK;
 constexpr int SLAB_WAVES = SLAB_BLOCK / 64;
 constexpr int SLAB_MAX_PASS = 16;
+constexpr int SLAB_ROUND = 32;              // chunks of a workgroup ordered before their slabs are staged (their pass starts live in LDS)
 constexpr size_t SLAB_MAX_TABLE = 2u << 20;
 
 struct SlabPlan {
@@ -69,10 +70,36 @@ __device__ __forceinline__ void slab_row_wait(T (&c)[O][ND])
         for (int dd = 0; dd < ND; ++dd) asm volatile("" : "+v"(c[k][dd]) :: "memory");
 }
 
-// window_contract's arithmetic (same operations in the same order: same bits) on rows read by slab_row_issue
+// b shifted left by P places, zero filled (P = the second variable's pad: a wave-uniform run-time value, dispatched once)
+template <typename T, int O, int P>
+__device__ __forceinline__ void slab_shift(const T (&b)[O], T (&bs)[O])
+{
+#pragma unroll
+    for (int k = 0; k < O; ++k) bs[k] = k + P < O ? b[k + P < O ? k + P : 0] : T(0);
+}
+
+// window_contract's arithmetic (same operations in the same order: same bits) on rows read by slab_row_issue.
+// MIXED: a second variable of lower order uses the LAST order1 columns of the O-wide window.  Testing `k >= pad1` per
+// term made hipcc select every accumulator update (120 of the 527 vector instructions per point of the fp64 order-5
+// loop were v_cndmask); instead the row reads START at column pad1 and the weights are shifted left by pad1 once: the
+// trailing columns carry weight zero and read finite values (the next control points of the slab; zero past its end).
 template <typename T, int O, int ND, bool MIXED>
 __device__ __forceinline__ void slab_window(unsigned w_addr, unsigned rstride, const int (&pad)[2], const T (&b)[2][O], T (&r)[ND])
 {
+    T b1[O];
+    if constexpr (MIXED) {
+        switch (pad[1]) {
+            case 0: slab_shift<T, O, 0>(b[1], b1); break;
+            case 1: slab_shift<T, O, 1>(b[1], b1); break;
+            case 2: slab_shift<T, O, (O > 2 ? 2 : 0)>(b[1], b1); break;
+            case 3: slab_shift<T, O, (O > 3 ? 3 : 0)>(b[1], b1); break;
+            case 4: slab_shift<T, O, (O > 4 ? 4 : 0)>(b[1], b1); break;
+            default: slab_shift<T, O, (O > 5 ? 5 : 0)>(b[1], b1); break;
+        }
+        w_addr += (unsigned)(pad[1] * ND * (int)sizeof(T));
+    } else {
+        slab_shift<T, O, 0>(b[1], b1);
+    }
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) r[dd] = T(0);
 #pragma unroll
@@ -85,12 +112,9 @@ __device__ __forceinline__ void slab_window(unsigned w_addr, unsigned rstride, c
 #pragma unroll
             for (int dd = 0; dd < ND; ++dd) t[dd] = T(0);
 #pragma unroll
-            for (int k = 0; k < O; ++k) {
-                if (!MIXED || k >= pad[1]) {
+            for (int k = 0; k < O; ++k)
 #pragma unroll
-                    for (int dd = 0; dd < ND; ++dd) t[dd] += c[k][dd] * b[1][k];
-                }
-            }
+                for (int dd = 0; dd < ND; ++dd) t[dd] += c[k][dd] * b1[k];
 #pragma unroll
             for (int dd = 0; dd < ND; ++dd) r[dd] += t[dd] * b[0][a];
         }
@@ -100,17 +124,19 @@ __device__ __forceinline__ void slab_window(unsigned w_addr, unsigned rstride, c
 // basis_bounded's recursion (same operations in the same order: same bits) on a SpanTab whose reads were issued for
 // the LARGEST order: a variable of lower order uses the entries of its own levels only (the others were read from
 // whatever lies there and are never touched).
-template <typename T, int OMAX>
+// DERIV = false: plain evaluation (wrt is 0): no value / derivative branches (their merges cost copies and selects:
+// 129 v_cndmask and 139 moves of the 597 vector instructions per point of the fp64 order-5 loop).
+template <typename T, int OMAX, bool DERIV>
 __device__ __forceinline__ void basis_regs_bounded(const SpanTab<T, OMAX> &t, int order, T u, int wrt, T (&r)[OMAX])
 {
 #pragma unroll
     for (int k = 0; k < OMAX; ++k) r[k] = T(0);
-    if (wrt >= order) return;
+    if (DERIV && wrt >= order) return;
     r[OMAX - 1] = T(1);
 #pragma unroll
     for (int degree = 1; degree < OMAX; ++degree) {
         if (degree < order) {
-            if (degree < order - wrt) {
+            if (!DERIV || degree < order - wrt) {
 #pragma unroll
                 for (int j = 0; j < degree; ++j) {
                     const int bi = OMAX - degree + j;
@@ -131,7 +157,7 @@ __device__ __forceinline__ void basis_regs_bounded(const SpanTab<T, OMAX> &t, in
     }
 }
 
-template <typename T, int O, int ND, bool MIXED>
+template <typename T, int O, int ND, bool MIXED, bool DERIV>
 __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const TileDesc<T> td, const SlabPlan sp,
                                                    const T *__restrict__ gtab, const unsigned *__restrict__ glut,
                                                    const T *__restrict__ aos, const Params<T> prm, const long long N,
@@ -160,10 +186,17 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const T *__restrict__ kn0 = gtab + d.off[0];              // knots of variable 0 (classification: through the vector L1)
     const long long nchunks = (N + SLAB_CHUNK - 1) / SLAB_CHUNK;
-    for (long long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // A ROUND = up to SLAB_ROUND of this workgroup's chunks (c, c + grid, ...): first every chunk of the round is
+    // ordered (phase 1), then every slab is staged ONCE per round and the points of all the round's chunks that fall in
+    // it are evaluated with no barrier between them (phase 2: the slab is static, the waves run free).  Staging a slab
+    // per chunk cost 21 us and three barriers per pass and chunk (10 M points, TomsNasty shape).
+    unsigned *rstart = pstart + (SLAB_MAX_PASS + 1);          // [chunk of the round][pass + 1]
+    for (long long cr = blockIdx.x; cr < nchunks; cr += (long long)gridDim.x * SLAB_ROUND) {
+    int nround = 0;
+    for (long long c = cr; c < nchunks && nround < SLAB_ROUND; c += gridDim.x, ++nround) {
         const long long lo = c * SLAB_CHUNK;
         const int cnt = (int)((N - lo) < SLAB_CHUNK ? (N - lo) : SLAB_CHUNK);
-        __syncthreads();                                     // tables staged (first chunk); the previous chunk's last pass is done with LDS
+        __syncthreads();                                     // tables staged (first chunk); the previous chunk's counters / the previous round's last pass are done with LDS
         {   // ---- phase 1: order the chunk by pass
             T pu[SLAB_PPT];
 #pragma unroll
@@ -198,6 +231,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
                 for (int g = 0; g < (int)threadIdx.x; ++g)
                     for (int w = 0; w < SLAB_WAVES; ++w) s += wcnt[w * SLAB_MAX_PASS + g];
                 pstart[threadIdx.x] = s;
+                rstart[nround * (SLAB_MAX_PASS + 1) + (int)threadIdx.x] = s;
             }
             __syncthreads();
             // first position of (wave, pass): one thread per pair turns the wave counts into exclusive prefixes over the waves
@@ -219,11 +253,10 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
                 }
             }
         }
-        // ---- phase 2: pass by pass
+    }
+        // ---- phase 2: slab by slab
         for (int g = 0; g < sp.npass; ++g) {
-            __syncthreads();                                 // scratch written (g = 0: the barrier drains this wave's stores) / previous pass's readers done
-            const int p0 = (int)pstart[g], p1 = (int)pstart[g + 1];
-            if (p0 == p1) continue;                          // (uniform: no point of this chunk in the pass)
+            __syncthreads();                                 // scratch written (g = 0: the barrier drains this wave's stores) / previous slab's readers done
             const int r0 = g * sp.spp;
             const int r1 = min(r0 + sp.rows, d.ncoef[0]);
             {   // the slab: rows r0 .. r1 of the control-point-major table, one contiguous copy; eight loads in flight per lane
@@ -248,6 +281,9 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
             const unsigned tab0_a = (unsigned)(size_t)stab0 - (unsigned)(r0 * (int)sizeof(T)), tab1_a = (unsigned)(size_t)stab1;
             // (register-tight instantiations - fp64 from order 5 on - read each point when they get to it)
             constexpr bool BOTH = 2 * ((O - 1) + O * (O - 1) / 2) * ((int)sizeof(T) / 4) <= 40;
+            for (int jr = 0; jr < nround; ++jr) {
+            const long long lo = (cr + (long long)jr * gridDim.x) * SLAB_CHUNK;
+            const int p0 = (int)rstart[jr * (SLAB_MAX_PASS + 1) + g], p1 = (int)rstart[jr * (SLAB_MAX_PASS + 1) + g + 1];
             // The point itself is read again from the caller's arrays at its batch position: the chunk's lines were
             // loaded by this CU a moment ago (L2 / Infinity Cache), and neighbours in a pass are near neighbours in
             // the batch - a scratch copy of {u, v} in pass order cost 160 MB of writes and reads per 10 M points more.
@@ -297,26 +333,26 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
                     span_tab_wait<T, O>(t0);
                     span_tab_wait<T, O>(t1);
                     if constexpr (MIXED) {
-                        basis_regs_bounded<T, O>(t0, d.order[0], q.u, wrt.w[0], b[0]);
-                        basis_regs_bounded<T, O>(t1, d.order[1], q.v, wrt.w[1], b[1]);
+                        basis_regs_bounded<T, O, DERIV>(t0, d.order[0], q.u, wrt.w[0], b[0]);
+                        basis_regs_bounded<T, O, DERIV>(t1, d.order[1], q.v, wrt.w[1], b[1]);
                     } else {
-                        basis_regs<T, O, true>(t0, q.u, wrt.w[0], b[0]);
-                        basis_regs<T, O, true>(t1, q.v, wrt.w[1], b[1]);
+                        basis_regs<T, O, DERIV>(t0, q.u, wrt.w[0], b[0]);
+                        basis_regs<T, O, DERIV>(t1, q.v, wrt.w[1], b[1]);
                     }
                 } else {
                     {
                         SpanTab<T, O> t0;
                         span_tab_issue<T, O>(tab0_a, sp.snk, i0, t0);
                         span_tab_wait<T, O>(t0);
-                        if constexpr (MIXED) basis_regs_bounded<T, O>(t0, d.order[0], q.u, wrt.w[0], b[0]);
-                        else basis_regs<T, O, true>(t0, q.u, wrt.w[0], b[0]);
+                        if constexpr (MIXED) basis_regs_bounded<T, O, DERIV>(t0, d.order[0], q.u, wrt.w[0], b[0]);
+                        else basis_regs<T, O, DERIV>(t0, q.u, wrt.w[0], b[0]);
                     }
                     {
                         SpanTab<T, O> t1;
                         span_tab_issue<T, O>(tab1_a, nk1, i1, t1);
                         span_tab_wait<T, O>(t1);
-                        if constexpr (MIXED) basis_regs_bounded<T, O>(t1, d.order[1], q.v, wrt.w[1], b[1]);
-                        else basis_regs<T, O, true>(t1, q.v, wrt.w[1], b[1]);
+                        if constexpr (MIXED) basis_regs_bounded<T, O, DERIV>(t1, d.order[1], q.v, wrt.w[1], b[1]);
+                        else basis_regs<T, O, DERIV>(t1, q.v, wrt.w[1], b[1]);
                     }
                 }
                 // right-aligned window: rows i0 - O .. i0 - 1 (the first pad[0] of them are neither weighted nor read)
@@ -332,6 +368,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
 #pragma unroll
                 for (int dd = 0; dd < ND; ++dd)
                     nt_store(&out[dd * ostride + n], r[dd]);
+            }
             }
         }
     }

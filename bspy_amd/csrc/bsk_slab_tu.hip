@@ -26,7 +26,7 @@ static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long lon
     sp.off_wcnt = (unsigned)off;
     off += up16(4 * (size_t)SLAB_WAVES * SLAB_MAX_PASS);
     sp.off_pstart = (unsigned)off;
-    off += up16(4 * (size_t)(SLAB_MAX_PASS + 1));
+    off += up16(4 * (size_t)(SLAB_MAX_PASS + 1) * (1 + SLAB_ROUND));   // pass starts of the chunk being ordered + of every chunk of the round
     sp.off_tab0 = (unsigned)off;
     const size_t lds_wg = s->lds_max;                             // one workgroup per CU
     if (off + 4096 > lds_wg) return BSK_ERR_UNSUPPORTED;
@@ -60,11 +60,19 @@ static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long lon
     static const int slab_dbg = getenv("BSK_SLAB_DBG") ? atoi(getenv("BSK_SLAB_DBG")) : 0;     // timing-only switches (tools/)
     const T *tab = static_cast<const T *>(s->tab);
     const T *aos = static_cast<const T *>(s->coef_aos);
+    bool deriv = false;
+    for (int iv = 0; iv < 2; ++iv) deriv |= w.w[iv] != 0;
 #define SLAB_ND(ND)                                                                                               \
     case ND:                                                                                                      \
-        HIPCHK(allow_lds(eval_slab2<T, O, ND, MIXED>, sp.total));                                                 \
-        hipLaunchKernelGGL((eval_slab2<T, O, ND, MIXED>), dim3(grid), dim3(SLAB_BLOCK), sp.total, st, d, td, sp, tab, s->lut, aos, prm, n, \
-                           0ll, spts, sidx, out, ostride, w, s->bad, slab_dbg);                                   \
+        if (deriv) {                                                                                              \
+            HIPCHK(allow_lds(eval_slab2<T, O, ND, MIXED, true>, sp.total));                                       \
+            hipLaunchKernelGGL((eval_slab2<T, O, ND, MIXED, true>), dim3(grid), dim3(SLAB_BLOCK), sp.total, st, d, td, sp, tab, s->lut, aos, \
+                               prm, n, 0ll, spts, sidx, out, ostride, w, s->bad, slab_dbg);                       \
+        } else {          /* plain evaluation: the recursions without their derivative branches */              \
+            HIPCHK(allow_lds(eval_slab2<T, O, ND, MIXED, false>, sp.total));                                      \
+            hipLaunchKernelGGL((eval_slab2<T, O, ND, MIXED, false>), dim3(grid), dim3(SLAB_BLOCK), sp.total, st, d, td, sp, tab, s->lut, aos, \
+                               prm, n, 0ll, spts, sidx, out, ostride, w, s->bad, slab_dbg);                       \
+        }                                                                                                         \
         break;
     switch (s->nDep) {
         SLAB_ND(1) SLAB_ND(2) SLAB_ND(3) SLAB_ND(4)
