@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
     BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + tab_b + bun_b);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(TILE_CAP + 4 * S2));
     unsigned *segs = hist + 2 * CS_MAX_S2;                  // segment start of every span
-    __shared__ int s_first;
+    __shared__ int s_first[CS_BLOCK / 64];
     int tile_no = 0;
     // Records per tile: with the padding of its S2 segments (0 .. 3 lanes each, 1.5 on average) a tile should fill the
     // wave passes of the workgroup (4 per wave) and not start one more that one wave runs while the others wait.
@@ -1255,19 +1255,25 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
     for (int i = threadIdx.x; i < 2 * CS_MAX_S2; i += blockDim.x) hist[i] = 0u;
     const long long per = (N + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
-    if (threadIdx.x == 0) {
-        int a = 0, b = bp.cells - 1;
-        while (a < b) {
-            const int m = (a + b + 1) >> 1;
-            if ((long long)start[m] <= lo) a = m; else b = m - 1;
-        }
-        s_first = a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        // first bin of the range: the last c with start[c] <= lo (start is non-decreasing).  Every lane probes its share in
+        // one round of independent loads (a binary search by one lane is a chain of a dozen dependent misses, ~10 us in
+        // front of every workgroup's first tile)
+        int best = 0;
+        for (int c = threadIdx.x; c < bp.cells; c += blockDim.x)
+            if ((long long)start[c] <= lo) best = c;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (lane == 0) s_first[wave] = best;
     }
     __syncthreads();
+    int first = 0;
+#pragma unroll
+    for (int i = 0; i < CS_BLOCK / 64; ++i) first = max(first, s_first[i]);
     const T *tab2 = stab + d.off[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cs0 = d.ncoef[1] * d.ncoef[2], cs1 = d.ncoef[2];   // table strides (control points)
-    for (int c = s_first; c < bp.cells && lo < hi; ++c) {
+    for (int c = first; c < bp.cells && lo < hi; ++c) {
         const long long cb = start[c], ce = c + 1 < bp.cells ? (long long)start[c + 1] : N;
         if (cb >= hi) break;
         const long long sl = cb > lo ? cb : lo, sh = ce < hi ? ce : hi;
@@ -1278,6 +1284,25 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
         span_tab_uniform<T, O>(stab + d.off[1], d.nk[1], q1 + O, st1);
         __syncthreads();                                     // previous bin's readers are done
         // bundle: row r = (i, j) of the bin's O x O control-point rows along the third variable
+        if constexpr (MFMA && ND == 4) {
+            // flat over the bundle's 16-byte elements, two independent loads per lane in flight (a wave per row is a
+            // chain of ROWS / 8 dependent round trips in front of the bin's first tile)
+            const int tot4 = ROWS * ncl;
+            for (int e0 = threadIdx.x; e0 < tot4; e0 += 2 * CS_BLOCK) {
+                float4 v[2];
+                int at[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = e0 + u * CS_BLOCK, ee = e < tot4 ? e : tot4 - 1;
+                    const int r = ee / ncl, k = ee - r * ncl, i = r / O, j = r - i * O;
+                    v[u] = *reinterpret_cast<const float4 *>(aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1 + k) * 4);
+                    at[u] = e < tot4 ? (k * ROWS + r) * 4 : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (at[u] >= 0) *reinterpret_cast<float4 *>(bun + at[u]) = v[u];
+            }
+        } else
         for (int r = wave; r < ROWS; r += CS_BLOCK / 64) {
             const int i = r / O, j = r - i * O;
             const T *__restrict__ src = aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1) * ND;
