@@ -260,6 +260,10 @@ __global__ __launch_bounds__(1024) void bin_scatter(const BinPlan bp, const Para
 //                     result from LDS at lpos[n] and the SoA rows are stored coalesced
 // ---------------------------------------------------------------------------------------------
 constexpr int WC_PPT = 8;             // points per lane of a 1024-lane workgroup: chunk <= 8192
+// the round-3 sort kernels (bin_totals, bin_scatter_tag, bin_unpermute_stream): an fp64 chunk is at most 4096 records
+// (32-byte records in 160 KB of LDS), so the lane holds half as many
+template <typename T>
+__host__ __device__ constexpr int wc_ppt() { return sizeof(T) == 8 ? WC_PPT / 2 : WC_PPT; }
 constexpr int BIN_MAX_WC_CELLS = 2048; // bins the write-combining kernels hold tables for
 
 template <typename T, int NIND>
@@ -513,13 +517,23 @@ __device__ __forceinline__ SpanLds<T> span_lds_stage(char *base, const Desc<T> &
     return sl;
 }
 
-template <typename T>
+template <typename T, int STEPS = 0>
 __device__ __forceinline__ int bin_of(const SpanLds<T> &sl, const Desc<T> &d, const TileDesc<T> &td, const BinPlan &bp, T u0, T u1)
 {
-    const int i0 = find_span_lut<T>(sl.kn[0], sl.lut, td, 0, d.lo[0], d.ncoef[0], u0) - d.order[0];
-    const int i1 = find_span_lut<T>(sl.kn[1], sl.lut, td, 1, d.lo[1], d.ncoef[1], u1) - d.order[1];
+    const int i0 = find_span_lut_n<T, STEPS>(sl.kn[0], sl.lut, td, 0, d.lo[0], d.ncoef[0], u0) - d.order[0];
+    const int i1 = find_span_lut_n<T, STEPS>(sl.kn[1], sl.lut, td, 1, d.lo[1], d.ncoef[1], u1) - d.order[1];
     return (i0 >> bp.sh0) * bp.n1 + (i1 >> bp.sh1);
 }
+
+// bisection steps the straight-line searches of a kernel need (0: more than two - the run-time loop)
+template <typename T>
+__device__ __forceinline__ int lut_steps_class(const TileDesc<T> &td, int nv)
+{
+    int m = 0;
+    for (int iv = 0; iv < nv; ++iv) m = max(m, td.lut_steps[iv]);
+    return m <= 1 ? 1 : m <= 2 ? 2 : 0;
+}
+template <int N> using cs_int = std::integral_constant<int, N>;
 
 // exclusive prefix over `cells` values held `per` consecutive ones per thread of a 1024-lane workgroup (v[i] of bin
 // t * per + i); returns the prefix of the thread's first bin.  s_wave: 16 words of LDS.  One barrier inside.
@@ -561,11 +575,12 @@ __global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDe
     __syncthreads();
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(V)));
+    const int steps = lut_steps_class<T>(td, 2);
     // chunks start at multiples of 8 points (host): 16-byte loads whenever the caller's arrays are 16-byte aligned
     const bool aligned = ((reinterpret_cast<size_t>(prm.p[0]) | reinterpret_cast<size_t>(prm.p[1])) & 15) == 0;
     // a chunk (<= 8192 points) is at most 2 (fp32) / 4 (fp64) vectors per lane and variable: the next chunk's are
     // requested before this chunk's are counted
-    constexpr int VPL = WC_PPT / V;
+    constexpr int VPL = wc_ppt<T>() / V;
     vecT a[VPL], bq[VPL];
     auto fetch = [&](int c) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
@@ -587,13 +602,24 @@ __global__ __launch_bounds__(1024) void bin_totals(const Desc<T> d, const TileDe
 #pragma unroll
         for (int k = 0; k < VPL; ++k) { ca[k] = a[k]; cb[k] = bq[k]; }
         if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);
+        // straight-line over the lane's points (a lane past the end classifies garbage and counts nothing): the searches'
+        // dependent LDS reads interleave
+        auto count = [&](auto S) {
+            constexpr int ST = decltype(S)::value;
+            int bn[VPL][V];
 #pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            if (k * 1024 + (int)threadIdx.x < nvec) {
+            for (int k = 0; k < VPL; ++k)
 #pragma unroll
-                for (int q = 0; q < V; ++q) atomicAdd(&hist[bin_of<T>(sl, d, td, bp, ca[k][q], cb[k][q])], 1u);
+                for (int q = 0; q < V; ++q) bn[k][q] = bin_of<T, ST>(sl, d, td, bp, ca[k][q], cb[k][q]);
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                if (k * 1024 + (int)threadIdx.x < nvec) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) atomicAdd(&hist[min(max(bn[k][q], 0), cells - 1)], 1u);
+                }
             }
-        }
+        };
+        if (steps == 1) count(cs_int<1>{}); else if (steps == 2) count(cs_int<2>{}); else count(cs_int<0>{});
         for (int i = nvec * V + (int)threadIdx.x; i < cnt; i += blockDim.x)
             atomicAdd(&hist[bin_of<T>(sl, d, td, bp, prm.p[0][lo + i], prm.p[1][lo + i])], 1u);
     }
@@ -729,14 +755,15 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
     const SpanLds<T> sl = span_lds_stage<T, 3>(tabs, d, td, gtab, glut);
     for (int i = threadIdx.x; i < cells; i += blockDim.x) cursor[i] = start[i] + rows[(size_t)blockIdx.x * cells + i];
     const int per = (cells + 1023) / 1024;
+    const int steps = lut_steps_class<T>(td, 3);
     // the NEXT chunk's points are requested at the top of an iteration (second register set): they stream in while
     // this chunk is counted, ordered and stored
-    T nu[WC_PPT], nv[WC_PPT], nw[WC_PPT];
+    T nu[wc_ppt<T>()], nv[wc_ppt<T>()], nw[wc_ppt<T>()];
     auto fetch = [&](int c) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
             const long long nn = lo + (i < cnt ? i : cnt - 1);
             nu[k] = __builtin_nontemporal_load(&prm.p[0][nn]);
@@ -749,9 +776,9 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
     for (; c < bp.chunks; c += gridDim.x) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
-        T pu[WC_PPT], pv[WC_PPT], pw[WC_PPT];
+        T pu[wc_ppt<T>()], pv[wc_ppt<T>()], pw[wc_ppt<T>()];
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) { pu[k] = nu[k]; pv[k] = nv[k]; pw[k] = nw[k]; }
+        for (int k = 0; k < wc_ppt<T>(); ++k) { pu[k] = nu[k]; pv[k] = nv[k]; pw[k] = nw[k]; }
         if (c + (int)gridDim.x < bp.chunks) fetch(c + (int)gridDim.x);
         __syncthreads();                                          // the previous chunk's store phase is done with LDS (first: tables, cursors staged)
         for (int i = threadIdx.x; i < cells; i += blockDim.x) lcnt[i] = 0u;
@@ -759,14 +786,18 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
         // bins and span keys of the lane's 8 points: straight-line code over all of them (a lane past the chunk's end
         // holds a copy of its last point), so that the 8 chains of dependent LDS reads interleave; only the domain
         // record and the histogram update are predicated
-        unsigned ck[WC_PPT], rk[WC_PPT], tg[WC_PPT];
+        unsigned ck[wc_ppt<T>()], rk[wc_ppt<T>()], tg[wc_ppt<T>()];
+        auto classify = [&](auto S) {
+            constexpr int ST = decltype(S)::value;
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) ck[k] = (unsigned)bin_of<T>(sl, d, td, bp, pu[k], pv[k]);
+            for (int k = 0; k < wc_ppt<T>(); ++k) ck[k] = (unsigned)min(max(bin_of<T, ST>(sl, d, td, bp, pu[k], pv[k]), 0), cells - 1);
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k)
-            tg[k] = (unsigned)(find_span_lut<T>(sl.kn[2], sl.lut, td, 2, d.lo[2], d.ncoef[2], pw[k]) - d.order[2]) << dest_bits;
+            for (int k = 0; k < wc_ppt<T>(); ++k)
+                tg[k] = (unsigned)(find_span_lut_n<T, ST>(sl.kn[2], sl.lut, td, 2, d.lo[2], d.ncoef[2], pw[k]) - d.order[2]) << dest_bits;
+        };
+        if (steps == 1) classify(cs_int<1>{}); else if (steps == 2) classify(cs_int<2>{}); else classify(cs_int<0>{});
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             rk[k] = 0u;
             if (k * 1024 + (int)threadIdx.x < cnt) {
                 const bool outside = (pu[k] < d.lo[0]) | (pu[k] > d.hi[0]) | (pv[k] < d.lo[1]) | (pv[k] > d.hi[1]) | (pw[k] < d.lo[2]) | (pw[k] > d.hi[2]);
@@ -791,7 +822,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_tag(const BinPlan bp, const 
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
             if (i < cnt) {
                 const unsigned p = (unsigned)locb[ck[k]] + rk[k];
@@ -823,13 +854,13 @@ __global__ __launch_bounds__(1024) void bin_unpermute_stream(const BinPlan bp, c
     BinOut<T, ND> *sout = reinterpret_cast<BinOut<T, ND> *>(smem);
     typedef T gvec __attribute__((ext_vector_type(BinOut<T, ND>::WORDS)));
     const int G = (int)gridDim.x;
-    gvec g[WC_PPT];
-    unsigned lpn[WC_PPT];
+    gvec g[wc_ppt<T>()];
+    unsigned lpn[wc_ppt<T>()];
     auto fetch = [&](int c) {
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             const int p0 = k * 1024 + (int)threadIdx.x, p = p0 < cnt ? p0 : cnt - 1;
             g[k] = *reinterpret_cast<const gvec *>(&tmp[lo + p]);
             lpn[k] = lpos[lo + p];
@@ -841,17 +872,17 @@ __global__ __launch_bounds__(1024) void bin_unpermute_stream(const BinPlan bp, c
         const long long lo = (long long)c * bp.chunk, hi = lo + bp.chunk < N ? lo + bp.chunk : N;
         const int cnt = (int)(hi - lo);
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             const int p = k * 1024 + (int)threadIdx.x;
             if (p < cnt) *reinterpret_cast<gvec *>(&sout[p]) = g[k];
         }
-        unsigned lp[WC_PPT];
+        unsigned lp[wc_ppt<T>()];
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) lp[k] = lpn[k];
+        for (int k = 0; k < wc_ppt<T>(); ++k) lp[k] = lpn[k];
         __syncthreads();
         if (c + G < bp.chunks) fetch(c + G);                   // the next chunk streams in while this one's rows are stored
 #pragma unroll
-        for (int k = 0; k < WC_PPT; ++k) {
+        for (int k = 0; k < wc_ppt<T>(); ++k) {
             const int i = k * 1024 + (int)threadIdx.x;
             if (i < cnt) {
                 const gvec r = *reinterpret_cast<const gvec *>(&sout[lp[k]]);

@@ -63,7 +63,7 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     const size_t out_sz = (4 * sizeof(T) + 15) / 16 * 16;          // BinOut<T, ND <= 4>
     long long chunk_max = (long long)((s->lds_max - bins_b - tabs_b - 256) / (sizeof(BinRec<T, 3>) + 2)) / 1024 * 1024;
     chunk_max = std::min<long long>(chunk_max, (long long)(s->lds_max / out_sz) / 1024 * 1024);
-    chunk_max = std::min<long long>(chunk_max, 1024 * WC_PPT);
+    chunk_max = std::min<long long>(chunk_max, 1024 * wc_ppt<T>());
     static const int env_wc = getenv("BSK_WC_CHUNK") ? atoi(getenv("BSK_WC_CHUNK")) : 0;                  // measurement knobs
     static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;
     if (env_wc > 0) chunk_max = std::min<long long>(chunk_max, std::max(1024, env_wc / 1024 * 1024));

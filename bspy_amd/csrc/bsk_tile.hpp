@@ -150,6 +150,33 @@ __device__ __forceinline__ int find_span_lut(KP knots, LP lut, const TileDesc<T>
     return (u != u) ? ncoef : l;
 }
 
+// The same search with a compile-time number of bisection steps (STEPS >= lut_steps[iv]: a step on a closed bracket
+// changes nothing): straight-line code, so that the searches of a lane's several points interleave their dependent
+// LDS reads - behind the run-time loop above they run one after the other.
+template <typename T, int STEPS, typename KP, typename LP>
+__device__ __forceinline__ int find_span_lut_n(KP knots, LP lut, const TileDesc<T> &td, int iv, T lo, int ncoef, T u)
+{
+    if constexpr (STEPS <= 0) {
+        return find_span_lut<T>(knots, lut, td, iv, lo, ncoef, u);
+    } else {
+        int b = (int)((u - lo) * td.lut_scale[iv]);
+        b = min(max(b, 0), td.lut_m[iv] - 1);
+        const unsigned e = lut[td.lut_off[iv] + b];
+        int l = (int)(e & 0xffffu), h = (int)(e >> 16);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int mid = (l + h) >> 1;
+            const T km = knots[mid];
+            const bool open = l < h;
+            const bool right = open && (km <= u);
+            const bool left = open && !right;
+            l = right ? mid + 1 : l;
+            h = left ? mid : h;
+        }
+        return (u != u) ? ncoef : l;
+    }
+}
+
 // Descriptor of the uniform-knot surface kernels (bsk_uniform.hpp): domain, span width, image layout.
 template <typename T>
 struct UniDesc {
