@@ -608,6 +608,30 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
         t.evaluate(bad)
     assert e.value.index == 123_456
     # the last variable is tested by the scatter kernel (the count kernel reads only the two that make the bin)
+    # NaN parameters (the reference's searchsorted puts them past the last span and returns NaN, no error): NaN at those
+    # points only - their bin / span keys are clamped inside the sort kernels and nobody else's slot moves
+    nan = [p.copy() for p in pts]
+    where = [(iv, 1_000 + 77_777 * iv) for iv in range(nind)]
+    for iv, i in where:
+        nan[iv][i] = np.nan
+    clean = t.evaluate(pts)
+    out = t.evaluate(nan)
+    hit = np.zeros(n, bool)
+    hit[[i for _, i in where]] = True
+    assert np.isnan(out[:, hit]).all()
+    assert np.array_equal(out[:, ~hit], clean[:, ~hit])
+    # points on every knot of every variable and one ulp either side, both ends of the domain included
+    edge = [p.copy() for p in pts]
+    for iv, k in enumerate(knots):
+        lo, hi = k[order[iv] - 1], k[ncoef[iv]]
+        d = np.unique(k)
+        e = np.concatenate((d, np.nextafter(d, dt(-np.inf)), np.nextafter(d, dt(np.inf)))).astype(dt)
+        e = e[(e >= lo) & (e <= hi)]
+        edge[iv][10_000 * (iv + 1): 10_000 * (iv + 1) + len(e)] = e
+    out = t.evaluate(edge)
+    orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0] * nind, [p[:40_000] for p in edge])
+    assert bad == -1
+    observe(f"cell order vs oracle, points on knots, {kind}", np.abs(out[:, :40_000] - orc).max() / _scale(orc), tol)
     bad = [p.copy() for p in pts]
     bad[-1][77_777] = np.nextafter(dt(knots[-1][ncoef[-1]]), dt(np.inf))
     bad[0][250_000] = dt(-9.0)
