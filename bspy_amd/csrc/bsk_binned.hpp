@@ -1250,12 +1250,84 @@ __device__ __forceinline__ void cs_contract(unsigned a_addr, unsigned r_addr, co
     cs_rows<O, ND, 0, AHEAD>(a_addr, r_addr, b0, b1, b0[0] * b1[0], buf, accg, accr);
 }
 
-// JAC: the fused jacobian - the evaluation body runs three times over the same sorted tile, once per unit derivative
-// request, and stores the partials of a record at tmp[j * N + dest]: one tile sort, one set of record reads and bundle
-// stagings instead of three.  (Sharing the value bases between the passes - six recursions instead of nine - needs five to
-// fifteen registers more than four waves per SIMD leave: measured 32 - 46 spilled registers in three arrangements.)
+// value and first-derivative bases of one variable from ONE recursion: the levels below the last are common, the last
+// level runs in its value and in its derivative form (the operations of basis_regs<.., true> with wrt 0 and wrt 1, in
+// the same order: same bits)
+template <typename T, int O>
+__device__ __forceinline__ void basis_regs_vd(const SpanTab<T, O> &t, T u, T (&b)[O], T (&db)[O])
+{
+#pragma unroll
+    for (int k = 0; k < O; ++k) b[k] = T(0);
+    b[O - 1] = T(1);
+#pragma unroll
+    for (int degree = 1; degree < O - 1; ++degree) {
+#pragma unroll
+        for (int j = 0; j < degree; ++j) {
+            const int bi = O - degree + j;
+            const T alpha = (u - t.kn[(O - 1) - degree + j]) * t.rc[degree][j];
+            b[bi - 1] += (T(1) - alpha) * b[bi];
+            b[bi] *= alpha;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < O; ++k) db[k] = b[k];
+    if constexpr (O > 1) {
+        constexpr int degree = O - 1;
+#pragma unroll
+        for (int j = 0; j < degree; ++j) {
+            const int bi = O - degree + j;
+            const T alpha = (u - t.kn[(O - 1) - degree + j]) * t.rc[degree][j];
+            b[bi - 1] += (T(1) - alpha) * b[bi];
+            b[bi] *= alpha;
+            const T beta = T(degree) * t.rc[degree][j];
+            db[bi - 1] -= beta * db[bi];
+            db[bi] *= beta;
+        }
+    }
+}
+
+// The fused jacobian's contraction: every row of the window is read ONCE and feeds three sets of accumulators - the
+// row weights db0_i b1_j, b0_i db1_j and b0_i b1_j (the third set is combined with db2 at the end).  One row in flight
+// ahead of the one in use.
+template <int O, int ND, int ROW>
+__device__ __forceinline__ void cs_rows3(unsigned a_addr, unsigned r_addr, const float (&b0)[O], const float (&d0)[O],
+                                         const float (&b1)[O], const float (&d1)[O], CsRow<O> (&buf)[2],
+                                         cs_f4 (&acc)[3][(O / 4) * ND + (O % 4) > 0 ? (O / 4) * ND + (O % 4) : 1])
+{
+    constexpr int ROWS = O * O, G = O / 4, R = O % 4;
+    if constexpr (ROW < ROWS) {
+        if constexpr (ROW + 1 < ROWS) cs_issue_row<O, ROW + 1>(a_addr, r_addr, buf[(ROW + 1) % 2]);
+        constexpr int i = ROW / O, j = ROW % O;
+        float w[3] = {d0[i] * b1[j], b0[i] * d1[j], b0[i] * b1[j]};
+        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) :: "memory");       // formed above the row's wait
+        CsRow<O> &row = buf[ROW % 2];
+        cs_wait_row<O, (ROW + 1 < ROWS) ? (G + R) : 0>(row);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if constexpr (G >= 1) {
+#pragma unroll
+                for (int dd = 0; dd < ND; ++dd) acc[s][dd] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.g[0][dd], w[s], acc[s][dd], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < R; ++r2)
+                acc[s][G * ND + r2] = __builtin_amdgcn_mfma_f32_4x4x1f32(row.r[r2], w[s], acc[s][G * ND + r2], 0, 0, 0);
+        }
+        cs_rows3<O, ND, ROW + 1>(a_addr, r_addr, b0, d0, b1, d1, buf, acc);
+    }
+}
+
+// lanes of an eval_cellsort workgroup: the fused jacobian keeps three sets of accumulators and both kinds of bases -
+// 161 registers, i.e. three waves per SIMD: three workgroups of four waves on a CU
+template <bool JAC>
+__host__ __device__ constexpr int cs_block() { return JAC ? 256 : CS_BLOCK; }
+
+// JAC: the fused jacobian - one tile sort and one set of record reads for the three partials of a record, stored at
+// tmp[j * N + dest].  Value and first-derivative bases of every variable come from one recursion (basis_regs_vd) and
+// every window row is read once for three sets of accumulators (cs_rows3): 161 registers, three waves per SIMD.
+// (Three passes of the plain body over the sorted tile at 125 registers / four waves per SIMD: 475 us per 10 M cfg5
+// points against 445; the same sharing squeezed into 128 registers spilled 32 - 46 of them in three arrangements.)
 template <typename T, int O, int ND, bool MFMA, bool DERIV = true, bool JAC = false>
-__global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
+__global__ __launch_bounds__(cs_block<JAC>()) __attribute__((amdgpu_waves_per_eu(JAC ? 3 : MFMA && O <= 5 ? 4 : 1, 8))) void eval_cellsort(const Desc<T> d, const BinPlan bp, const T *__restrict__ gtab,
                                                      const T *__restrict__ aos, const unsigned *__restrict__ start,
                                                      const BinRec<T, 3> *__restrict__ rec, const long long N,
                                                      BinOut<T, ND> *__restrict__ tmp, const Wrt wrt, const int dest_bits)
@@ -1267,8 +1339,9 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
     const int ncl = d.ncoef[2];
     const int S2 = ncl - d.order[2] + 1;
     constexpr int ROWS = O * O;
+    constexpr int BLK = cs_block<JAC>();
     constexpr int PER = cs_per<T>();                        // records per lane and tile
-    constexpr int TILE_CAP = PER * CS_BLOCK;
+    constexpr int TILE_CAP = PER * BLK;
     constexpr int DP = MFMA ? 4 : ND;                       // dependent-variable slots of a bundle row
     const size_t tab_b = (sizeof(T) * (size_t)d.tab_len + 15) & ~(size_t)15;
     const size_t bun_b = (sizeof(T) * (size_t)ROWS * DP * ncl + 15) & ~(size_t)15;
@@ -1277,7 +1350,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
     BinRec<T, 3> *srec = reinterpret_cast<BinRec<T, 3> *>(smem + tab_b + bun_b);
     unsigned *hist = reinterpret_cast<unsigned *>(smem + tab_b + bun_b + sizeof(BinRec<T, 3>) * (size_t)(TILE_CAP + 4 * S2));
     unsigned *segs = hist + 2 * CS_MAX_S2;                  // segment start of every span
-    __shared__ int s_first[CS_BLOCK / 64];
+    __shared__ int s_first[BLK / 64];
     int tile_no = 0;
     // Records per tile: with the padding of its S2 segments (0 .. 3 lanes each, 1.5 on average) a tile should fill the
     // wave passes of the workgroup (4 per wave) and not start one more that one wave runs while the others wait.
@@ -1301,7 +1374,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
     __syncthreads();
     int first = 0;
 #pragma unroll
-    for (int i = 0; i < CS_BLOCK / 64; ++i) first = max(first, s_first[i]);
+    for (int i = 0; i < BLK / 64; ++i) first = max(first, s_first[i]);
     const T *tab2 = stab + d.off[2];
     const int cs0 = d.ncoef[1] * d.ncoef[2], cs1 = d.ncoef[2];   // table strides (control points)
     for (int c = first; c < bp.cells && lo < hi; ++c) {
@@ -1319,12 +1392,12 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
             // flat over the bundle's 16-byte elements, two independent loads per lane in flight (a wave per row is a
             // chain of ROWS / 8 dependent round trips in front of the bin's first tile)
             const int tot4 = ROWS * ncl;
-            for (int e0 = threadIdx.x; e0 < tot4; e0 += 2 * CS_BLOCK) {
+            for (int e0 = threadIdx.x; e0 < tot4; e0 += 2 * BLK) {
                 float4 v[2];
                 int at[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int e = e0 + u * CS_BLOCK, ee = e < tot4 ? e : tot4 - 1;
+                    const int e = e0 + u * BLK, ee = e < tot4 ? e : tot4 - 1;
                     const int r = ee / ncl, k = ee - r * ncl, i = r / O, j = r - i * O;
                     v[u] = *reinterpret_cast<const float4 *>(aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1 + k) * 4);
                     at[u] = e < tot4 ? (k * ROWS + r) * 4 : -1;
@@ -1334,7 +1407,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     if (at[u] >= 0) *reinterpret_cast<float4 *>(bun + at[u]) = v[u];
             }
         } else
-        for (int r = wave; r < ROWS; r += CS_BLOCK / 64) {
+        for (int r = wave; r < ROWS; r += BLK / 64) {
             const int i = r / O, j = r - i * O;
             const T *__restrict__ src = aos + ((long long)(q0 + i) * cs0 + (long long)(q1 + j) * cs1) * ND;
             if constexpr (MFMA) {
@@ -1366,7 +1439,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
             cs_rec4 rc[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const long long p = t0 + i * CS_BLOCK + (long long)threadIdx.x;
+                const long long p = t0 + i * BLK + (long long)threadIdx.x;
                 // read once: non-temporal (214 -> 207 us)
                 rc[i] = __builtin_nontemporal_load(reinterpret_cast<const cs_rec4 *>(&rec[p < sh ? p : sh - 1]));
             }
@@ -1375,7 +1448,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
             unsigned rank[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int idx = i * CS_BLOCK + (int)threadIdx.x;
+                const int idx = i * BLK + (int)threadIdx.x;
                 key[i] = -1;
                 if (idx < cnt) {
                     // found by the scatter kernel.  (Clamped: a tag is DATA from another kernel; no index formed from it
@@ -1427,17 +1500,16 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
             }
             __syncthreads();                                 // (B) tile in span order
             // --- evaluation in span order
-            for (int g = wave * 64; g < total; g += CS_BLOCK) {
+            for (int g = wave * 64; g < total; g += BLK) {
                 const int q = g + lane;
                 const bool live = q < total;
                 const BinRec<T, 3> r = srec[live ? q : total - 1];
                 const unsigned tag = word_tag<T>(r.v[3]);
                 const int ix2 = min((int)(tag >> dest_bits), S2 - 1);
                 const unsigned dest = tag & dest_mask;
-                // JAC: the body below once per variable j with the unit derivative request e_j (a real loop: the sorted tile,
-                // the record and the scalar span tables are shared; registers as in the derivative kernel)
-                auto body = [&](const int j) __attribute__((always_inline)) {
-                const int w0 = JAC ? (int)(j == 0) : wrt.w[0], w1 = JAC ? (int)(j == 1) : wrt.w[1], w2 = JAC ? (int)(j == 2) : wrt.w[2];
+                // (the fused jacobian has its own body below)
+                auto body = [&]() __attribute__((always_inline)) {
+                const int w0 = wrt.w[0], w1 = wrt.w[1], w2 = wrt.w[2];
                 T b[3][O];
                 SpanTab<T, O> st2;
                 span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
@@ -1465,9 +1537,7 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     for (int q2 = 0; q2 < R; ++q2) accr[q2] = cs_f4{0.f, 0.f, 0.f, 0.f};
                     const unsigned a_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + (lane & 3)) * (ROWS * 16));
                     const unsigned r_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + 4 * G) * (ROWS * 16) + (lane & 3) * 4);
-                    // (JAC: reads one row ahead instead of four - the record and its addresses live across the three
-                    // passes and need the registers; the depth measured no different on the value kernel)
-                    cs_contract<O, ND, JAC ? 1 : CS_AHEAD>(a_addr, r_addr, b[0], b[1], accg, accr);
+                    cs_contract<O, ND, CS_AHEAD>(a_addr, r_addr, b[0], b[1], accg, accr);
 #pragma unroll
                     for (int dd = 0; dd < ND; ++dd) {
                         T sum = T(0);
@@ -1487,14 +1557,53 @@ __global__ __launch_bounds__(CS_BLOCK) __attribute__((amdgpu_waves_per_eu(MFMA &
                     BinOut<T, ND> o;
 #pragma unroll
                     for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = k < ND ? res[k < ND ? k : 0] : T(0);
-                    tmp[(JAC ? (long long)j * N : 0ll) + dest] = o;   // chunk order (bin_unpermute_stream); (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
+                    tmp[dest] = o;   // chunk order (bin_unpermute_stream); (un-sorting the tile's results through LDS for whole-line stores: 297 -> 394 us)
                 }
                 };
-                if constexpr (JAC) {
-#pragma unroll 1
-                    for (int j = 0; j < 3; ++j) body(j);
+                if constexpr (JAC && MFMA) {
+                    // fused jacobian: value and first-derivative bases of the three variables (three recursions with a
+                    // doubled last level), every window row read once for three sets of accumulators (cs_rows3)
+                    T bv[3][O], bd[3][O];
+                    basis_regs_vd<T, O>(st0, r.v[0], bv[0], bd[0]);
+                    basis_regs_vd<T, O>(st1, r.v[1], bv[1], bd[1]);
+                    constexpr int G = O / 4, R = O % 4, NA = G * ND + R > 0 ? G * ND + R : 1;
+                    cs_f4 acc[3][NA];
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                        for (int q2 = 0; q2 < NA; ++q2) acc[s3][q2] = cs_f4{0.f, 0.f, 0.f, 0.f};
+                    const unsigned a_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + (lane & 3)) * (ROWS * 16));
+                    const unsigned r_addr = (unsigned)(size_t)bun + (unsigned)((ix2 + 4 * G) * (ROWS * 16) + (lane & 3) * 4);
+                    CsRow<O> buf[2];
+                    cs_issue_row<O, 0>(a_addr, r_addr, buf[0]);
+                    cs_rows3<O, ND, 0>(a_addr, r_addr, bv[0], bd[0], bv[1], bd[1], buf, acc);
+                    {   // the third variable's bases after the contraction: ten registers fewer while 15 accumulators are live
+                        SpanTab<T, O> st2;
+                        span_tab_issue<T, O>((unsigned)(size_t)tab2, d.nk[2], ix2 + O, st2);
+                        span_tab_wait<T, O>(st2);
+                        basis_regs_vd<T, O>(st2, r.v[2], bv[2], bd[2]);
+                    }
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3) {
+                        const T (&b2)[O] = s3 == 2 ? bd[2] : bv[2];
+                        BinOut<T, ND> o;
+#pragma unroll
+                        for (int k = 0; k < BinOut<T, ND>::WORDS; ++k) o.v[k] = T(0);
+#pragma unroll
+                        for (int dd = 0; dd < ND; ++dd) {
+                            T sum = T(0);
+#pragma unroll
+                            for (int g2 = 0; g2 < G; ++g2)
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) sum += b2[4 * g2 + m] * acc[s3][g2 * ND + dd][m];
+#pragma unroll
+                            for (int r2 = 0; r2 < R; ++r2) sum += b2[4 * G + r2] * acc[s3][G * ND + r2][dd];
+                            o.v[dd] = sum;
+                        }
+                        if (live && (long long)dest < N) tmp[(long long)s3 * N + dest] = o;
+                    }
                 } else {
-                    body(0);                                     // (no loop around the plain kernels: a one-trip loop kept by the pragma cost them 10 %)
+                    body();
                 }
             }
             asm volatile("" :: "v"(touch));

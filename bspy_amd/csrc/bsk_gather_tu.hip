@@ -120,13 +120,14 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
                                s->lut, dest_bits, s->bad);
             stage_mark(s, st, "bin_scatter_tag");
         }
-        const int cgrid = (int)std::max<long long>(1, std::min<long long>((np + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : 4)));
+        const size_t cs_lds_jac = cs_lds_mfma - 4 * sizeof(T) * (size_t)cs_per<T>() * (CS_BLOCK - cs_block<true>());   // shorter tiles
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((np + 4 * CS_BLOCK - 1) / (4 * CS_BLOCK), (long long)s->num_cu * (env_cs > 0 ? env_cs : jac ? 6 : 4)));   // (fused jacobian: three workgroups resident per CU)
 #define CS_ND(ND)                                                                                                        \
     case ND: {                                                                                                           \
         BinOut<T, ND> *tmp = reinterpret_cast<BinOut<T, ND> *>(ws + o_tmp);                                              \
         if constexpr (MF) if (jac) {                                                                                     \
-            HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true, MF>, cs_lds_mfma));                                       \
-            hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true, MF>), dim3(cgrid), dim3(CS_BLOCK), cs_lds_mfma, st, d,  \
+            HIPCHK(allow_lds(eval_cellsort<T, O, ND, MF, true, MF>, cs_lds_jac));                                        \
+            hipLaunchKernelGGL((eval_cellsort<T, O, ND, MF, true, MF>), dim3(cgrid), dim3(cs_block<true>()), cs_lds_jac, st, d,  \
                                bp, tab, aos, start, rec, np, tmp, w, dest_bits);                                         \
         }                                                                                                                \
         if (jac) {                                                                                                       \
