@@ -1270,7 +1270,7 @@ __device__ __forceinline__ void basis_regs_vd(const SpanTab<T, O> &t, T u, T (&b
         }
     }
 #pragma unroll
-    for (int k = 0; k < O; ++k) db[k] = b[k];
+    for (int k = 0; k < O; ++k) db[k] = O > 1 ? b[k] : T(0);     // (order 1: the derivative of a piecewise constant is zero)
     if constexpr (O > 1) {
         constexpr int degree = O - 1;
 #pragma unroll

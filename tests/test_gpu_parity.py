@@ -1127,6 +1127,40 @@ def test_cfg4_full_size(golden_tables):
     assert torch.equal(pos2, bspy_amd.tessellate_tables(tabs, (g, g), normals=False))
 
 
+@pytest.mark.parametrize("order,ndep", [(1, 2), (2, 1), (2, 4), (3, 3), (4, 1), (4, 4), (5, 2), (5, 4), (6, 3)])
+def test_fused_jacobian_in_cell_order(order, ndep):
+    """eval_cellsort<..., JAC> (fp32, three variables of one order): value and derivative bases from one recursion, every
+    window row read once for three accumulator sets.  Every order and several nDep against the oracle and against the three
+    derivative passes of the same pipeline; clustered points, points on knots, determinism."""
+    rng = np.random.default_rng(100 * order + ndep)
+    ncoef = (order + 35, order + 31, order + 37)                # tables beyond LDS: the cell-order pipeline
+    knots = [cases.nonuniform_knots(rng, order, c, np.float32, 0.0, 1.0) for c in ncoef]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(np.float32)
+    n = 280_003
+    pts = [rng.random(n).astype(np.float32) for _ in range(3)]
+    pts[2][: n // 4] = np.float32(0.4321)
+    for iv, k in enumerate(knots):
+        d = np.unique(k)
+        e = np.concatenate((d, np.nextafter(d, np.float32(-1)), np.nextafter(d, np.float32(2)))).astype(np.float32)
+        e = e[(e >= 0) & (e <= 1)]
+        pts[iv][100_000 + 1_000 * iv: 100_000 + 1_000 * iv + len(e)] = e
+    t = DeviceSpline((order,) * 3, ncoef, knots, coefs, np.float32)
+    jac = t.jacobian(pts)
+    assert "fused jacobian" in t.last_kernel(), t.last_kernel()
+    assert jac.shape == (ndep, 3, n)
+    sample = np.concatenate((rng.choice(n, 15_000, replace=False), np.arange(100_000, 103_000)))
+    ojac, bad = oracle.c_jacobian((order,) * 3, ncoef, knots, coefs, [p[sample] for p in pts])
+    assert bad == -1
+    observe("fused jacobian (cell order) vs fp32 oracle", np.abs(jac[:, :, sample] - ojac).max() / _scale(ojac), 2e-5)
+    for j in range(3):
+        w = [0, 0, 0]
+        w[j] = 1
+        dj = t.evaluate(pts, w)
+        assert "eval_cellsort" in t.last_kernel()
+        observe("fused jacobian vs derivative passes (cell order)", np.abs(jac[:, j] - dj).max() / _scale(dj), 2e-5)
+    assert np.array_equal(jac, t.jacobian(pts))
+
+
 @pytest.mark.parametrize("ncoef,ndep,knots_kind", [((64, 64), 3, "uniform"), ((4, 4), 3, "bezier"), ((9, 23), 1, "nonuniform"),
                                                     ((37, 16), 4, "nonuniform"), ((12, 12), 2, "uniform")])
 def test_fp32_bicubic_records(ncoef, ndep, knots_kind):
