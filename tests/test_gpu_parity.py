@@ -1127,6 +1127,66 @@ def test_cfg4_full_size(golden_tables):
     assert torch.equal(pos2, bspy_amd.tessellate_tables(tabs, (g, g), normals=False))
 
 
+def _lut_steps(knots, order, ncoef):
+    """Bisection steps the library's bucket table of this knot vector needs (bsk_api.hip build_lut: 4 x spans buckets,
+    brackets widened by 1 % of a bucket; the smaller table is only taken when one step suffices)."""
+    k = np.asarray(knots, np.float64)
+    lo, hi = k[order - 1], k[ncoef]
+    m = 16
+    while m < 4 * (ncoef - order + 1) and m < 4096:
+        m <<= 1
+    inv = (hi - lo) / m
+    span = lambda x: order + int(np.searchsorted(k[order:ncoef], x, side="right"))
+    widest = 0
+    for b in range(m):
+        l = span(lo + (b - 0.01) * inv)
+        h = ncoef if b == m - 1 else span(lo + (b + 1.01) * inv)
+        widest = max(widest, h - l)
+    return int(np.ceil(np.log2(widest + 1)))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("style,steps_class", [("uniform", 1), ("ratio20", 2), ("graded", 0)])
+def test_sort_kernels_span_search_forms(style, steps_class, dt):
+    """bin_totals / bin_scatter_tag search spans with a compile-time number of bisection steps (1 or 2) or, for knot vectors
+    whose buckets hold more spans, the run-time loop: one knot style per form, fp32 (MFMA evaluation, 8 points per lane in
+    the sort kernels) and fp64 (4 per lane), against the oracle and bitwise-deterministic; out-of-domain index."""
+    rng = np.random.default_rng(5)
+    order, ncoef, ndep = (3, 3, 3), (42, 40, 44), 2
+    knots = []
+    for o, c in zip(order, ncoef):
+        s = c - o + 1
+        if style == "uniform":
+            inner = np.linspace(0.0, 1.0, s + 1)
+        elif style == "ratio20":                                 # spans of width 1 and 20 alternating in blocks of three
+            wdt = np.where((np.arange(s) // 3) % 2 == 0, 1.0, 20.0)
+            inner = np.concatenate(([0.0], np.cumsum(wdt))) / wdt.sum()
+        else:                                                    # spans shrinking towards the left end: a dozen in one bucket
+            inner = (np.arange(s + 1) / s) ** 4
+        knots.append(np.concatenate(([inner[0]] * (o - 1), inner, [inner[-1]] * (o - 1))).astype(dt))
+    steps = max(_lut_steps(k, o, c) for k, o, c in zip(knots, order, ncoef))
+    assert (steps if steps <= 2 else 0) == steps_class, steps
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+    n = 270_001
+    pts = [rng.random(n).astype(dt) for _ in range(3)]
+    if style == "graded":
+        pts[0][: n // 2] = (rng.random(n // 2) ** 4).astype(dt)   # half the batch in the crowded end
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    out = t.evaluate(pts)
+    assert "eval_cellsort" in t.last_kernel(), t.last_kernel()
+    sample = rng.choice(n, 30_000, replace=False)
+    orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0, 0], [p[sample] for p in pts])
+    assert bad == -1
+    kind = "fp32" if dt == np.float32 else "fp64"
+    observe(f"cell order, span search forms, vs oracle, {kind}", np.abs(out[:, sample] - orc).max() / _scale(orc), 2e-5 if dt == np.float32 else 1e-12)
+    assert np.array_equal(out, t.evaluate(pts))
+    bad = [p.copy() for p in pts]
+    bad[2][200_001] = dt(1.5)
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 200_001
+
+
 @pytest.mark.parametrize("order,ndep", [(1, 2), (2, 1), (2, 4), (3, 3), (4, 1), (4, 4), (5, 2), (5, 4), (6, 3)])
 def test_fused_jacobian_in_cell_order(order, ndep):
     """eval_cellsort<..., JAC> (fp32, three variables of one order): value and derivative bases from one recursion, every
