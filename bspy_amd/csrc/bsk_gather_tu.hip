@@ -68,7 +68,10 @@ static bsk_status launch_cellsort_pipeline(bsk_spline s, BinPlan bp, const Param
     static const int env_cs = getenv("BSK_CS_GRID") ? atoi(getenv("BSK_CS_GRID")) : 0;
     if (env_wc > 0) chunk_max = std::min<long long>(chunk_max, std::max(1024, env_wc / 1024 * 1024));
     if (chunk_max < 2048) return BSK_ERR_UNSUPPORTED;
-    const long long piece_max = (((1ll << dest_bits) - 1) / 1024) * 1024;
+    long long piece_max = (((1ll << dest_bits) - 1) / 1024) * 1024;
+    const char *env_piece_s = getenv("BSK_CS_PIECE");                                                     // test knob: short pieces (read per call)
+    const long long env_piece = env_piece_s ? atoll(env_piece_s) : 0;
+    if (env_piece > 0) piece_max = std::min(piece_max, std::max(8192ll, env_piece / 1024 * 1024));
     const long long pieces = (n + piece_max - 1) / piece_max;
     const long long piece = std::min(n, (((n + pieces - 1) / pieces) + 1023) / 1024 * 1024);
     const size_t lds_tot = ((span_lds_bytes<T, 2>(d, td) + 15) & ~(size_t)15) + 4 * (size_t)bp.cells;

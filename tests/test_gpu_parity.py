@@ -1127,6 +1127,31 @@ def test_cfg4_full_size(golden_tables):
     assert torch.equal(pos2, bspy_amd.tessellate_tables(tabs, (g, g), normals=False))
 
 
+def test_cell_order_pipeline_in_pieces(monkeypatch):
+    """A batch beyond 2^dest_bits points (67 M, or 16.7 M when the third variable has more than 64 spans) runs the pipeline
+    piece by piece.  BSK_CS_PIECE shortens the pieces so that a 300 k batch takes four of them (ragged last one): same
+    bits as the one-piece run for evaluate, a derivative and the fused jacobian; first offender in the last piece."""
+    rng = np.random.default_rng(8)
+    order, ncoef, ndep = (3, 3, 3), (40, 38, 90), 3               # 88 spans in the third variable: 24 destination bits
+    knots = [cases.nonuniform_knots(rng, o, c, np.float32, 0.0, 1.0) for o, c in zip(order, ncoef)]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(np.float32)
+    n = 300_011
+    pts = [rng.random(n).astype(np.float32) for _ in range(3)]
+    whole = DeviceSpline(order, ncoef, knots, coefs, np.float32)
+    ref = [whole.evaluate(pts), whole.evaluate(pts, [0, 1, 1]), whole.jacobian(pts)]
+    assert "fused jacobian" in whole.last_kernel()
+    monkeypatch.setenv("BSK_CS_PIECE", "90000")                  # (read by the library at every call)
+    t = DeviceSpline(order, ncoef, knots, coefs, np.float32)
+    got = [t.evaluate(pts), t.evaluate(pts, [0, 1, 1]), t.jacobian(pts)]
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    bad = [p.copy() for p in pts]
+    bad[1][299_999] = np.float32(-0.5)
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 299_999
+
+
 def _lut_steps(knots, order, ncoef):
     """Bisection steps the library's bucket table of this knot vector needs (bsk_api.hip build_lut: 4 x spans buckets,
     brackets widened by 1 % of a bucket; the smaller table is only taken when one step suffices)."""
