@@ -56,7 +56,8 @@ static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long lon
     SlabPt<T> *spts = nullptr;                                    // (the points are read again from the caller's arrays)
     unsigned *sidx = reinterpret_cast<unsigned *>(s->bin_ws.p);
     const long long nchunks = (n + SLAB_CHUNK - 1) / SLAB_CHUNK;
-    const int grid = (int)std::min<long long>(nchunks, (long long)s->num_cu);
+    int grid = (int)std::min<long long>(nchunks, (long long)s->num_cu);
+    if (const char *g = getenv("BSK_SLAB_GRID")) grid = std::max(1, std::min(grid, atoi(g)));          // test knob: few workgroups = several rounds each
     static const int slab_dbg = getenv("BSK_SLAB_DBG") ? atoi(getenv("BSK_SLAB_DBG")) : 0;     // timing-only switches (tools/)
     const T *tab = static_cast<const T *>(s->tab);
     const T *aos = static_cast<const T *>(s->coef_aos);

@@ -1152,6 +1152,37 @@ def test_cell_order_pipeline_in_pieces(monkeypatch):
     assert e.value.index == 299_999
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_slab_kernel_rounds(dt, monkeypatch):
+    """eval_slab2 orders up to 32 chunks of a workgroup per ROUND and starts another round after them - only batches beyond
+    67 M points reach a second round on 256 CUs.  BSK_SLAB_GRID = 1 makes one workgroup take all 37 chunks of a 300 k batch
+    (two rounds, the second with 5 chunks, the last chunk ragged), 3 gives 13 / 12 / 12: same bits as the full grid, for
+    evaluate and a derivative; offender index in the second round."""
+    rng = np.random.default_rng(9)
+    order, ncoef, ndep = (4, 5), (900 if dt == np.float64 else 1800, 11), 3      # the TomsNasty shape (238 KB: three passes); twice the rows in fp32
+    knots = [cases.nonuniform_knots(rng, o, c, dt, 0.0, 1.0) for o, c in zip(order, ncoef)]
+    coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
+    n = 300_017
+    pts = [rng.random(n).astype(dt) for _ in range(2)]
+    t = DeviceSpline(order, ncoef, knots, coefs, dt)
+    ref = [t.evaluate(pts), t.evaluate(pts, [1, 2])]
+    assert t.last_kernel() == "eval_slab2", t.last_kernel()
+    orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, [1, 2], [p[:20_000] for p in pts])
+    assert bad == -1
+    kind = "fp32" if dt == np.float32 else "fp64"
+    observe(f"eval_slab2 vs oracle, derivative (1, 2), {kind}", np.abs(ref[1][:, :20_000] - orc).max() / _scale(orc), 2e-5 if dt == np.float32 else 1e-12)
+    for grid in ("1", "3"):
+        monkeypatch.setenv("BSK_SLAB_GRID", grid)
+        assert np.array_equal(t.evaluate(pts), ref[0]), grid
+        assert np.array_equal(t.evaluate(pts, [1, 2]), ref[1]), grid
+    bad = [p.copy() for p in pts]
+    bad[0][299_000] = dt(2.0)                                     # chunk 36: the second round of the only workgroup
+    monkeypatch.setenv("BSK_SLAB_GRID", "1")
+    with pytest.raises(bspy_amd.DomainError) as e:
+        t.evaluate(bad)
+    assert e.value.index == 299_000
+
+
 def _lut_steps(knots, order, ncoef):
     """Bisection steps the library's bucket table of this knot vector needs (bsk_api.hip build_lut: 4 x spans buckets,
     brackets widened by 1 % of a bucket; the smaller table is only taken when one step suffices)."""
