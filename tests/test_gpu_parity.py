@@ -361,11 +361,11 @@ def test_full_size_properties():
     assert np.abs(jac[:, 1] - d1).max() <= 1e-11 * _scale(d1)
 
 
-@pytest.mark.parametrize("n", [50_000_000, 6_250_000])
+@pytest.mark.parametrize("n", [50_000_000, 6_250_000, 70_000_000])
 def test_cfg5_full_size_properties(n):
-    """BASELINE configs[4] at its real size: 50 M points on the trivariate order-5 40^3 x 4 fp32 spline (two pieces of
-    the cell-order pipeline: a record's tag holds 26 bits of destination), and the 6.25 M-point shard one of 8 GPUs
-    gets.  Device-resident I/O.  Oracle on a 200 k sample spread over the batch (the end of it included), bitwise
+    """BASELINE configs[4] at its real size: 50 M points on the trivariate order-5 40^3 x 4 fp32 spline, the 6.25 M-point
+    shard one of 8 GPUs gets, and 70 M points - beyond the 2^26 destinations a record's tag holds, so the cell-order
+    pipeline runs two pieces of 35 M.  Device-resident I/O.  Oracle on a 200 k sample spread over the batch (the end of it included), bitwise
     determinism, bitwise permutation equivariance, partition of unity, and the first offender near the END of the batch
     (32-bit slot / chunk arithmetic)."""
     torch = pytest.importorskip("torch")
