@@ -258,6 +258,11 @@ extern "C" bsk_status bsk_spline_create(bsk_dtype dtype, int device, int nInd, i
         bool fixed = nInd <= 3 && omax <= 6;                  // gather / cell-order kernels: any mix of orders <= 6
         if (fixed && nDep <= 4 && tbytes + 8192 > s->lds_max)
             HIPCHK_C(hipMalloc(&s->coef_aos, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+        else if (fixed && nDep <= 4 && nInd == 2 && !s->same_order && omax >= 2) {
+            // LDS-resident surface of mixed orders: eval_slab2 in one pass (explicit LDS reads) reads the same layout
+            HIPCHK_C(hipMalloc(&s->coef_aos, std::max<size_t>(16, s->esize * (size_t)coef_len)));
+            s->aos_small = true;
+        }
     }
     HIPCHK_C(hipMalloc((void **)&s->lut, std::max<size_t>(16, sizeof(unsigned) * (size_t)(dtype == BSK_F32 ? s->t32.lut_len : s->t64.lut_len))));
     HIPCHK_C(hipMalloc((void **)&s->bad, sizeof(unsigned long long)));
@@ -1071,8 +1076,10 @@ static bsk_status dispatch_eval(bsk_spline s, const Params<T> &prm, long long n,
         int omax = 0;
         for (int iv = 0; iv < s->nInd; ++iv) omax = std::max(omax, s->order[iv]);
         if (!s->same_order && omax >= 2 && omax <= 6 && s->coef_aos) {
-            // table too large for LDS: control-point-major gather / cell-order pipeline at O = omax
-            const bsk_status r = gather_or_binned_any<T>(s, true, prm, n, out, ostride, w, st);
+            // table too large for LDS: control-point-major gather / cell-order pipeline at O = omax; an LDS-resident
+            // surface: eval_slab2 with the whole table as its one slab (batches below 65536 points: eval_mixed)
+            const bsk_status r = s->aos_small ? slab2_any<T>(s, true, prm, n, out, ostride, w, st)
+                                              : gather_or_binned_any<T>(s, true, prm, n, out, ostride, w, st);
             if (r != BSK_ERR_UNSUPPORTED) return r;
         }
         // eval_mixed: surfaces up to order 8, volumes up to 6, curves up to 12, four variables up to order 4, five up to 3

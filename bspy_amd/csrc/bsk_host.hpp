@@ -65,6 +65,7 @@ struct bsk_spline_s {
     int nInd, nDep;
     int order[MAXI], ncoef[MAXI];
     bool same_order;         // every variable has the same order
+    bool aos_small = false;  // coef_aos exists although the table fits LDS: mixed-order surfaces run eval_slab2 in one pass
     size_t esize;
     Desc<float> d32;
     Desc<double> d64;

@@ -191,12 +191,23 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
     // it are evaluated with no barrier between them (phase 2: the slab is static, the waves run free).  Staging a slab
     // per chunk cost 21 us and three barriers per pass and chunk (10 M points, TomsNasty shape).
     unsigned *rstart = pstart + (SLAB_MAX_PASS + 1);          // [chunk of the round][pass + 1]
+    // The whole table in ONE slab (LDS-resident tables of mixed orders, which have no explicit-read kernel of their own):
+    // no ordering phase and no order scratch - a lane's points are its batch positions, its results coalesced stores.
+    // (MIXED instantiations only: same-order LDS-resident surfaces have their own kernels and never come here, and the
+    // order-6 fp32 instantiation has no register left for the extra branch)
+    const bool single = MIXED && sp.npass == 1;
     for (long long cr = blockIdx.x; cr < nchunks; cr += (long long)gridDim.x * SLAB_ROUND) {
     int nround = 0;
     for (long long c = cr; c < nchunks && nround < SLAB_ROUND; c += gridDim.x, ++nround) {
         const long long lo = c * SLAB_CHUNK;
         const int cnt = (int)((N - lo) < SLAB_CHUNK ? (N - lo) : SLAB_CHUNK);
         __syncthreads();                                     // tables staged (first chunk); the previous chunk's counters / the previous round's last pass are done with LDS
+        if (single) {                                        // one pass: nothing to order - phase 2 takes the chunk in batch order
+            if (threadIdx.x == 0) {
+                rstart[nround * (SLAB_MAX_PASS + 1)] = 0u;
+                rstart[nround * (SLAB_MAX_PASS + 1) + 1] = (unsigned)cnt;
+            }
+        } else
         {   // ---- phase 1: order the chunk by pass
             T pu[SLAB_PPT];
 #pragma unroll
@@ -296,18 +307,22 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
                 qn.u = prm.p[0][lo + (en & 0xffffu)];
                 qn.v = prm.p[1][lo + (en & 0xffffu)];
             };
-            if (p < p1) { en = sidx[lo + p]; if (BOTH) fetch_pt(); }
-            if (p + SLAB_BLOCK < p1) en2 = sidx[lo + p + SLAB_BLOCK];
+            if (p < p1) { en = single ? (unsigned)p : sidx[lo + p]; if (BOTH) fetch_pt(); }
+            if (p + SLAB_BLOCK < p1) en2 = single ? (unsigned)(p + SLAB_BLOCK) : sidx[lo + p + SLAB_BLOCK];
             if (dbg & 1) p = p1;
             for (; p < p1; p += SLAB_BLOCK) {
                 if (!BOTH) fetch_pt();
                 const SlabPt<T> q = qn;
                 const unsigned e = en;
                 en = en2;
-                if (p + 2 * SLAB_BLOCK < p1) en2 = sidx[lo + p + 2 * SLAB_BLOCK];
+                if (p + 2 * SLAB_BLOCK < p1) en2 = single ? (unsigned)(p + 2 * SLAB_BLOCK) : sidx[lo + p + 2 * SLAB_BLOCK];
                 if (BOTH && p + SLAB_BLOCK < p1) fetch_pt();                // the next point streams in meanwhile
                 if ((q.v < d.lo[1]) | (q.v > d.hi[1])) record_bad(bad, base + lo + (long long)(e & 0xffffu));
-                const int i0 = (int)(e >> 16);
+                int i0 = (int)(e >> 16);
+                if (single) {                                // (phase 1 did not run: the span and the domain test of variable 0 here;
+                    if ((q.u < d.lo[0]) | (q.u > d.hi[0])) record_bad(bad, base + lo + (long long)(e & 0xffffu));   //  row 0 of the staged axis table = all knots)
+                    i0 = find_span_lut<T>(stab0, slut, td, 0, d.lo[0], d.ncoef[0], q.u);
+                }
                 const int i1 = find_span_lut<T>(stab1, slut, td, 1, d.lo[1], d.ncoef[1], q.v);
                 T b[2][O];
                 // fp64 at order 6: neither the span tables nor a window row fit the registers beside the rest - that
