@@ -32,9 +32,11 @@ class ShardedEvaluator:
     ``spline``      a ``bspy_amd.Spline`` (or anything with its attributes)
     ``group``       torch.distributed process group (default: WORLD)
     ``collectives_at_world1``  run the collectives in a one-rank group too (tests)
-    ``local_eval``  optional ``f(op, points, wrt) -> array (rows, m)`` replacing the local
-                    GPU evaluation (tests inject a CPU checker under gloo); ``op`` is
-                    "evaluate" or "jacobian".  Default: this rank's DeviceSpline.
+    ``local_eval``  TEST SEAM, not a product feature: optional ``f(op, points, wrt) -> array (rows, m)``
+                    replacing the local GPU evaluation, so that the world-size-2 ``gloo`` tests can run
+                    the sharding and collective logic on a machine without a GPU (they inject the CPU
+                    checker there).  ``op`` is "evaluate" or "jacobian".  Nothing in the package passes
+                    it; the default - and the only product path - is this rank's DeviceSpline.
     """
 
     def __init__(self, spline, group=None, local_eval=None, device=None, collectives_at_world1=False):
