@@ -2044,12 +2044,15 @@ static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *co
     constexpr long long VEC = 16 / (long long)sizeof(T);
     const int vec_ok = (g.n[1] % VEC == 0) && ((reinterpret_cast<uintptr_t>(dpos) & 15) == 0) &&
                        ((reinterpret_cast<uintptr_t>(dnrm) & 15) == 0) ? 1 : 0;
-    const size_t lds = sizeof(T) * 3 * (size_t)s->ncoef[1] * 2;
+    const size_t lds = sizeof(T) * 3 * (size_t)s->ncoef[1] * std::max(2, TESS_R);     // contracted rows: [2] with normals, [TESS_R] rows without
     for (int p0 = 0; p0 < count; p0 += TESS_MAX_PATCHES) {
         const int np = std::min(TESS_MAX_PATCHES, count - p0);
         PatchCoefs<T> pc;
         for (int i = 0; i < TESS_MAX_PATCHES; ++i) pc.c[i] = i < np ? static_cast<const T *>(sp[p0 + i]->coef) : nullptr;
-        const int gx = (int)std::max<long long>(1, std::min<long long>(g.n[0], std::max<long long>(1, (long long)s->num_cu * 8 / np)));
+        // (the positions-only form with hoisted column bases takes TESS_R grid rows per workgroup iteration: same test as in the kernel)
+        const bool hoist = !normals && vec_ok && s->same_order && g.n[1] <= 256 * VEC * 2;
+        const long long row_units = hoist ? (g.n[0] + TESS_R - 1) / TESS_R : g.n[0];
+        const int gx = (int)std::max<long long>(1, std::min<long long>(row_units, std::max<long long>(1, (long long)s->num_cu * 8 / np)));
         T *pp = dpos + (size_t)p0 * 3 * (size_t)total;
         T *pn = dnrm ? dnrm + (size_t)p0 * 3 * (size_t)total : nullptr;
 #define TESS_LAUNCH(O, NRM, MIX)                                                                                       \

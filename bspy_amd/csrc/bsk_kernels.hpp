@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void grid_rows(const Desc<T> d, const T *__res
 // blockIdx.y = patch.  pos / nrm [((patch * 3 + dep) * n0 + i0) * n1 + i1]
 // ---------------------------------------------------------------------------------
 constexpr int TESS_MAX_PATCHES = 64;
+constexpr int TESS_R = 4;               // grid rows per barrier pair of the hoisted (positions-only) form
 template <typename T>
 struct PatchCoefs {
     const T *c[TESS_MAX_PATCHES];
@@ -660,6 +661,82 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
             }
         }
     }
+    if (hoist) {
+        // TESS_R grid rows per barrier pair: the two dependent global round trips in front of a row's contraction (span
+        // index, then the control points it selects) and the barriers are paid once per 4 rows = 96 KB of stores; a lane
+        // whose columns share a span reads its contracted control points once.  Same box, alternating runs: 0.339 - 0.344
+        // -> 0.333 - 0.335 ms for the 32 x 2048^2 job (4.8 TB/s; a linear fill of the same 1.6 GB runs at 6.9 TB/s,
+        // tools/write_floor.py - the 96 result planes are written through ~3000 concurrent streams)
+        const int rsz = 3 * nc1;
+        for (long long ib = (long long)blockIdx.x * TESS_R; ib < g.n[0]; ib += (long long)gridDim.x * TESS_R) {
+            const int nr = (int)((g.n[0] - ib) < TESS_R ? (g.n[0] - ib) : TESS_R);
+            __syncthreads();                                   // the previous rows' readers are done
+            for (int e = threadIdx.x; e < nr * rsz; e += blockDim.x) {
+                const int r = e / rsz, e2 = e - r * rsz, dep = e2 / nc1, c = e2 - dep * nc1;
+                const long long i0 = ib + r;
+                const int ix0 = ixs[g.goff[0] + i0];
+                const T *__restrict__ col = gcoef + dep * d.cstride[0] + (ix0 - O) * s0 + c;
+                T acc = T(0);
+#pragma unroll
+                for (int a = 0; a < O; ++a) acc += rows[g.roff[0] + i0 * O + a] * col[a * s0];
+                rowc[r * rsz + e2] = acc;
+            }
+            __syncthreads();
+            for (int r = 0; r < nr; ++r) {
+                const long long i0 = ib + r;
+                const bool bad0 = outside[g.goff[0] + i0] != 0;
+                const T *rowr = rowc + r * rsz;
+#pragma unroll
+                for (int it = 0; it < HIT; ++it) {
+                    const long long c0 = ((long long)it * blockDim.x + threadIdx.x) * VEC;
+                    if (c0 < n1) {
+                        T P[3][VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            if (blockIdx.y == 0 && (bad0 | hbad[it][v])) record_bad(bad, i0 * n1 + c0 + v);
+                        if (hix1[it][0] == hix1[it][VEC - 1]) {
+                            // the lane's columns lie in one span (always, for Bezier patches): its 3 x O contracted control
+                            // points are read once for the VEC columns (LDS instructions per point: 3 O -> 3 O / VEC)
+                            T rcv[3][O];
+#pragma unroll
+                            for (int dep = 0; dep < 3; ++dep)
+#pragma unroll
+                                for (int k = 0; k < O; ++k) rcv[dep][k] = rowr[dep * nc1 + hix1[it][0] + k];
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                                for (int dep = 0; dep < 3; ++dep) {
+                                    T p = T(0);
+#pragma unroll
+                                    for (int k = 0; k < O; ++k) p += rcv[dep][k] * hb1[it][v][k];
+                                    P[dep][v] = p;
+                                }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+                                for (int dep = 0; dep < 3; ++dep) {
+                                    const T *rc = rowr + dep * nc1 + hix1[it][v];
+                                    T p = T(0);
+#pragma unroll
+                                    for (int k = 0; k < O; ++k) p += rc[k] * hb1[it][v][k];
+                                    P[dep][v] = p;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int dep = 0; dep < 3; ++dep) {
+                            vec_t w;
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) w[v] = P[dep][v];
+                            __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(ppos + dep * total + i0 * n1 + c0));   // (plain stores: 0.302 -> 0.319 ms)
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (long long i0 = blockIdx.x; i0 < g.n[0]; i0 += gridDim.x) {
         const int ix0 = ixs[g.goff[0] + i0];
         const bool bad0 = outside[g.goff[0] + i0] != 0;
@@ -687,50 +764,6 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
             if constexpr (NORMALS) drowc[e] = dacc;
         }
         __syncthreads();
-        if (hoist) {
-#pragma unroll
-            for (int it = 0; it < HIT; ++it) {
-                const long long c0 = ((long long)it * blockDim.x + threadIdx.x) * VEC;
-                if (c0 < n1) {
-                    T P[3][VEC], Nn[3][VEC];
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        if (blockIdx.y == 0 && (bad0 | hbad[it][v])) record_bad(bad, i0 * n1 + c0 + v);
-                        T su[3], sv[3];
-#pragma unroll
-                        for (int dep = 0; dep < 3; ++dep) {
-                            const T *rc = rowc + dep * nc1 + hix1[it][v];
-                            const T *drc = drowc + dep * nc1 + hix1[it][v];
-                            T p = T(0), u_ = T(0), v_ = T(0);
-#pragma unroll
-                            for (int k = 0; k < O; ++k) {
-                                p += rc[k] * hb1[it][v][k];
-                                if constexpr (NORMALS) { u_ += drc[k] * hb1[it][v][k]; v_ += rc[k] * hdb1[it][v][k]; }
-                            }
-                            P[dep][v] = p; su[dep] = u_; sv[dep] = v_;
-                        }
-                        if constexpr (NORMALS) {
-                            T nn[3];
-                            tess_normal<T>(su, sv, normalize, negate, nn);
-                            Nn[0][v] = nn[0]; Nn[1][v] = nn[1]; Nn[2][v] = nn[2];
-                        }
-                    }
-#pragma unroll
-                    for (int dep = 0; dep < 3; ++dep) {
-                        vec_t w;
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) w[v] = P[dep][v];
-                        __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(ppos + dep * total + i0 * n1 + c0));
-                        if constexpr (NORMALS) {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) w[v] = Nn[dep][v];
-                            __builtin_nontemporal_store(w, reinterpret_cast<vec_t *>(pnrm + dep * total + i0 * n1 + c0));
-                        }
-                    }
-                }
-            }
-            continue;
-        }
         const long long step = vec_ok ? VEC : 1;
         for (long long c0 = (long long)threadIdx.x * step; c0 < n1; c0 += (long long)blockDim.x * step) {
             T P[3][VEC], Nn[3][VEC];
