@@ -2044,23 +2044,30 @@ static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *co
     constexpr long long VEC = 16 / (long long)sizeof(T);
     const int vec_ok = (g.n[1] % VEC == 0) && ((reinterpret_cast<uintptr_t>(dpos) & 15) == 0) &&
                        ((reinterpret_cast<uintptr_t>(dnrm) & 15) == 0) ? 1 : 0;
-    const size_t lds = sizeof(T) * 3 * (size_t)s->ncoef[1] * std::max(2, TESS_R);     // contracted rows: [2] with normals, [TESS_R] rows without
+    const int tess_r = getenv("BSK_TESS_R") ? std::max(1, std::min(64, atoi(getenv("BSK_TESS_R")))) : TESS_R;      // measurement knobs
+    const int tess_t = getenv("BSK_TESS_T") ? atoi(getenv("BSK_TESS_T")) : 512;
+    const int tess_w = getenv("BSK_TESS_W") ? std::max(1, atoi(getenv("BSK_TESS_W"))) : 0;                          // 256-lane workgroups per CU (0: 8, or 2 for the 512-lane form = one workgroup per CU: the fewer streams are written at a time, the better the memory side does - 0.287 / 0.255 / 0.239 ms at 8 / 4 / 2)
+    const size_t lds = sizeof(T) * 3 * (size_t)s->ncoef[1] * std::max(2, tess_r);     // contracted rows: [2] with normals, [tess_r] rows without
     for (int p0 = 0; p0 < count; p0 += TESS_MAX_PATCHES) {
         const int np = std::min(TESS_MAX_PATCHES, count - p0);
         PatchCoefs<T> pc;
         for (int i = 0; i < TESS_MAX_PATCHES; ++i) pc.c[i] = i < np ? static_cast<const T *>(sp[p0 + i]->coef) : nullptr;
         // (the positions-only form with hoisted column bases takes TESS_R grid rows per workgroup iteration: same test as in the kernel)
         const bool hoist = !normals && vec_ok && s->same_order && g.n[1] <= 256 * VEC * 2;
-        const long long row_units = hoist ? (g.n[0] + TESS_R - 1) / TESS_R : g.n[0];
-        const int gx = (int)std::max<long long>(1, std::min<long long>(row_units, std::max<long long>(1, (long long)s->num_cu * 8 / np)));
+        const bool wide = hoist && tess_t == 512 && g.n[1] <= 512 * VEC;       // 512 lanes, one hoisted step per lane
+        const long long row_units = hoist ? (g.n[0] + tess_r - 1) / tess_r : g.n[0];
+        const int gx = (int)std::max<long long>(1, std::min<long long>(row_units, std::max<long long>(1, (long long)s->num_cu * (tess_w ? tess_w : wide ? 2 : 8) / (wide ? 2 : 1) / np)));
         T *pp = dpos + (size_t)p0 * 3 * (size_t)total;
         T *pn = dnrm ? dnrm + (size_t)p0 * 3 * (size_t)total : nullptr;
 #define TESS_LAUNCH(O, NRM, MIX)                                                                                       \
     hipLaunchKernelGGL((tess_rows<T, O, NRM, MIX>), dim3(gx, np), dim3(256), lds, st, d, pc, g, ixs, rows,             \
-                       NRM ? drows : rows, outside, pp, pn, s->bad, vec_ok, normalize, negate)
+                       NRM ? drows : rows, outside, pp, pn, s->bad, vec_ok, normalize, negate, tess_r)
+#define TESS_LAUNCH_WIDE(O)                                                                                            \
+    hipLaunchKernelGGL((tess_rows<T, O, false, false, 1>), dim3(gx, np), dim3(512), lds, st, d, pc, g, ixs, rows,      \
+                       rows, outside, pp, pn, s->bad, vec_ok, normalize, negate, tess_r)
 #define TESS(O)                                                                                                        \
     case O:                                                                                                            \
-        if (s->same_order) { if (normals) TESS_LAUNCH(O, true, false); else TESS_LAUNCH(O, false, false); }            \
+        if (s->same_order) { if (normals) TESS_LAUNCH(O, true, false); else if (wide) TESS_LAUNCH_WIDE(O); else TESS_LAUNCH(O, false, false); } \
         else { if (normals) TESS_LAUNCH(O, true, true); else TESS_LAUNCH(O, false, true); }                            \
         break;
         switch (std::max(s->order[0], s->order[1])) {
@@ -2069,6 +2076,7 @@ static bsk_status run_tessellate(const bsk_spline *sp, int count, const void *co
         }
 #undef TESS
 #undef TESS_LAUNCH
+#undef TESS_LAUNCH_WIDE
     }
     HIPCHK(hipGetLastError());
     if (mem == BSK_HOST) {

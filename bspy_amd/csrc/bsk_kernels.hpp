@@ -615,12 +615,14 @@ __device__ __forceinline__ void tess_normal(const T (&su)[3], const T (&sv)[3], 
 }
 
 // MIXED: the two variables have different orders o0, o1 <= O (as grid_rows).
-template <typename T, int O, bool NORMALS, bool MIXED>
-__global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoefs<T> pc, const GridDims g,
+// HIT: hoisted vector steps per lane of the positions-only form - 2 at 256 lanes, 1 at 512 lanes (half the hoisted
+// registers: twice the waves per SIMD)
+template <typename T, int O, bool NORMALS, bool MIXED, int HIT = 2>
+__global__ __launch_bounds__(HIT == 1 ? 512 : 256) void tess_rows(const Desc<T> d, const PatchCoefs<T> pc, const GridDims g,
                                                  const int *__restrict__ ixs, const T *__restrict__ rows,
                                                  const T *__restrict__ drows, const unsigned char *__restrict__ outside,
                                                  T *__restrict__ pos, T *__restrict__ nrm, unsigned long long *bad,
-                                                 const int vec_ok, const int normalize, const int negate)
+                                                 const int vec_ok, const int normalize, const int negate, const int tess_r)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     const int nc1 = d.ncoef[1], s0 = d.cstride[1];
@@ -637,7 +639,6 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
     // enough (two vector steps per lane) their span indices and basis rows of the second variable are taken
     // into registers ONCE, and a row then costs LDS reads of the contracted row, multiply-adds and stores only
     // (before: 21 B of L2 reads per 12 B written).
-    constexpr int HIT = 2;                                       // hoisted vector steps per lane
     // (positions only: with normals the second basis row per column costs the registers that four waves per
     // SIMD need - measured 0.78 -> 1.07 ms)
     const bool hoist = !NORMALS && vec_ok && !MIXED && n1 <= (long long)blockDim.x * VEC * HIT;
@@ -664,12 +665,15 @@ __global__ __launch_bounds__(256) void tess_rows(const Desc<T> d, const PatchCoe
     if (hoist) {
         // TESS_R grid rows per barrier pair: the two dependent global round trips in front of a row's contraction (span
         // index, then the control points it selects) and the barriers are paid once per 4 rows = 96 KB of stores; a lane
-        // whose columns share a span reads its contracted control points once.  Same box, alternating runs: 0.339 - 0.344
-        // -> 0.333 - 0.335 ms for the 32 x 2048^2 job (4.8 TB/s; a linear fill of the same 1.6 GB runs at 6.9 TB/s,
-        // tools/write_floor.py - the 96 result planes are written through ~3000 concurrent streams)
+        // whose columns share a span reads its contracted control points once; 512 lanes with one hoisted step each
+        // (70 registers, 7 waves per SIMD) instead of 256 with two (106 registers).  tools/tess_sweep.py, one placement
+        // of the 1.6 GB result, interleaved medians: 0.341 (round-2 form) -> 0.329 (256 lanes) -> 0.312 - 0.316 ms (512
+        // lanes, 2 - 4 workgroups per CU).  The PLACEMENT of the result moves every variant by +- 12 % from run to run
+        // (0.25 - 0.33 ms for one build); a linear fill of the same bytes runs at 6.9 TB/s (tools/write_floor.py)
         const int rsz = 3 * nc1;
-        for (long long ib = (long long)blockIdx.x * TESS_R; ib < g.n[0]; ib += (long long)gridDim.x * TESS_R) {
-            const int nr = (int)((g.n[0] - ib) < TESS_R ? (g.n[0] - ib) : TESS_R);
+        // (every patch starting at another row unit - the planes lie a power of two apart - measured no different)
+        for (long long ib = (long long)blockIdx.x * tess_r; ib < g.n[0]; ib += (long long)gridDim.x * tess_r) {
+            const int nr = (int)((g.n[0] - ib) < tess_r ? (g.n[0] - ib) : tess_r);
             __syncthreads();                                   // the previous rows' readers are done
             for (int e = threadIdx.x; e < nr * rsz; e += blockDim.x) {
                 const int r = e / rsz, e2 = e - r * rsz, dep = e2 / nc1, c = e2 - dep * nc1;
