@@ -640,7 +640,7 @@ __global__ __launch_bounds__(HIT == 1 ? 512 : 256) void tess_rows(const Desc<T> 
     // into registers ONCE, and a row then costs LDS reads of the contracted row, multiply-adds and stores only
     // (before: 21 B of L2 reads per 12 B written).
     // (positions only: with normals the second basis row per column costs the registers that four waves per
-    // SIMD need - measured 0.78 -> 1.07 ms)
+    // SIMD need - measured 0.78 -> 1.07 ms at 256 lanes, 0.78 -> 0.89 ms in the 512-lane form at 256 registers)
     const bool hoist = !NORMALS && vec_ok && !MIXED && n1 <= (long long)blockDim.x * VEC * HIT;
     T hb1[HIT][VEC][O], hdb1[NORMALS ? HIT : 1][NORMALS ? VEC : 1][O];
     int hix1[HIT][VEC];
