@@ -214,6 +214,7 @@ def other_configs(torch, tables, u, v, n):
         # two shapes VERDICT r2 named (not BASELINE configs): the reference's examples/TomsNasty.json shape and an all-fp32 bicubic
         rng = np.random.default_rng(3)
         for key, order2, ncoef2, dt2, bpe in (("surface_o4x5_900x11_f64_TomsNasty_shape", (4, 5), (900, 11), np.float64, 40),
+                                              ("surface_o3x4_20x20_f64_mixed_orders", (3, 4), (20, 20), np.float64, 40),
                                               ("bicubic_64x64_f32", (4, 4), (64, 64), np.float32, 20)):
             k2 = [cases.clamped_uniform_knots(o, c, dt2) for o, c in zip(order2, ncoef2)]
             t2 = bspy_amd.DeviceSpline(order2, ncoef2, k2, rng.standard_normal((3, *ncoef2)).astype(dt2), dt2)
