@@ -38,6 +38,7 @@ constexpr size_t SLAB_MAX_TABLE = 2u << 20;
 struct SlabPlan {
     int spp;          // spans of the first variable per pass
     int npass;
+    int chunk;      // points per chunk: SLAB_CHUNK, or less for a one-slab table on a batch that would not fill the CUs
     int rows;         // rows of a slab (spp + order0 - 1)
     int snk;          // entries per row of the axis-table slice (spp + order0)
     unsigned off_lut, off_wcnt, off_pstart, off_tab0, off_slab, total;   // byte offsets in LDS
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
     pad[1] = O - d.order[1];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const T *__restrict__ kn0 = gtab + d.off[0];              // knots of variable 0 (classification: through the vector L1)
-    const long long nchunks = (N + SLAB_CHUNK - 1) / SLAB_CHUNK;
+    const int chunk = sp.chunk;                              // SLAB_CHUNK; shorter for one-slab tables on small batches (host)
+    const long long nchunks = (N + chunk - 1) / chunk;
     // A ROUND = up to SLAB_ROUND of this workgroup's chunks (c, c + grid, ...): first every chunk of the round is
     // ordered (phase 1), then every slab is staged ONCE per round and the points of all the round's chunks that fall in
     // it are evaluated with no barrier between them (phase 2: the slab is static, the waves run free).  Staging a slab
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
     for (long long cr = blockIdx.x; cr < nchunks; cr += (long long)gridDim.x * SLAB_ROUND) {
     int nround = 0;
     for (long long c = cr; c < nchunks && nround < SLAB_ROUND; c += gridDim.x, ++nround) {
-        const long long lo = c * SLAB_CHUNK;
-        const int cnt = (int)((N - lo) < SLAB_CHUNK ? (N - lo) : SLAB_CHUNK);
+        const long long lo = c * chunk;
+        const int cnt = (int)((N - lo) < chunk ? (N - lo) : chunk);
         __syncthreads();                                     // tables staged (first chunk); the previous chunk's counters / the previous round's last pass are done with LDS
         if (single) {                                        // one pass: nothing to order - phase 2 takes the chunk in batch order
             if (threadIdx.x == 0) {
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(SLAB_BLOCK) void eval_slab2(const Desc<T> d, const 
             // (register-tight instantiations - fp64 from order 5 on - read each point when they get to it)
             constexpr bool BOTH = 2 * ((O - 1) + O * (O - 1) / 2) * ((int)sizeof(T) / 4) <= 40;
             for (int jr = 0; jr < nround; ++jr) {
-            const long long lo = (cr + (long long)jr * gridDim.x) * SLAB_CHUNK;
+            const long long lo = (cr + (long long)jr * gridDim.x) * chunk;
             const int p0 = (int)rstart[jr * (SLAB_MAX_PASS + 1) + g], p1 = (int)rstart[jr * (SLAB_MAX_PASS + 1) + g + 1];
             // The point itself is read again from the caller's arrays at its batch position: the chunk's lines were
             // loaded by this CU a moment ago (L2 / Infinity Cache), and neighbours in a pass are near neighbours in

@@ -514,8 +514,7 @@ def test_launch_and_host_chunk_loops():
         outs.append((np.load(f), np.load(f + ".host.npy"), np.load(f + ".host4.npy")))
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
-    # the mixed-order surface: whole batches of >= 65536 points run eval_slab2 (one pass), the 40 000-point chunks
-    # eval_mixed - the same operations, multiply-adds contracted differently
+    # the mixed-order surface (batches of >= 2^20 points would run eval_slab2 in one slab; these are on eval_mixed either way)
     observe("mixed-order surface, chunked vs whole host batch", np.abs(outs[0][2] - outs[1][2]).max() / _scale(outs[0][2]), 1e-13)
 
 
@@ -1160,14 +1159,14 @@ def test_cell_order_pipeline_in_pieces(monkeypatch):
                                                   ((5, 3), (12, 40), 4, np.float32), ((4, 6), (25, 14), 2, np.float32),
                                                   ((1, 4), (16, 16), 3, np.float64), ((6, 2), (9, 33), 2, np.float64)])
 def test_mixed_order_surfaces_in_one_slab(order, ncoef, ndep, dt, monkeypatch):
-    """LDS-resident surfaces of mixed orders: batches of >= 65536 points run eval_slab2 with the whole table as its one slab
+    """LDS-resident surfaces of mixed orders: batches of >= 2^20 points run eval_slab2 with the whole table as its one slab
     (no ordering phase, batch-order results) instead of the compiler-managed eval_mixed.  Every derivative multi-index up
     to total order 2 (+ one beyond an order), points on every knot +- 1 ulp, against the oracle and eval_mixed
     (BSK_VARIANT=7); ragged last chunk; NaN; first offender."""
     rng = np.random.default_rng(sum(order) * 10 + ndep)
     knots = [cases.nonuniform_knots(rng, o, c, dt, -1.0, 1.0) for o, c in zip(order, ncoef)]
     coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
-    n = 70_003
+    n = 1_100_003
     pts = []
     for k, o, c in zip(knots, order, ncoef):
         lo, hi = k[o - 1], k[c]
@@ -1182,30 +1181,31 @@ def test_mixed_order_surfaces_in_one_slab(order, ncoef, ndep, dt, monkeypatch):
     plain = DeviceSpline(order, ncoef, knots, coefs, dt)
     kind = "fp32" if dt == np.float32 else "fp64"
     tol = 2e-5 if dt == np.float32 else 1e-12
+    sample = np.unique(np.concatenate((np.arange(0, 3_000), rng.integers(0, n, 40_000), np.arange(n - 3_000, n))))   # the knot points, a random part, the ragged end
     for w in cases.all_wrt(2, 2) + [(max(order), 0), (0, min(order))]:
         out = t.evaluate(pts, list(w))
         assert t.last_kernel() == "eval_slab2", t.last_kernel()
-        orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, list(w), pts)
+        orc, bad = oracle.c_evaluate(order, ncoef, knots, coefs, list(w), [p[sample] for p in pts])
         assert bad == -1
-        observe(f"eval_slab2 (one slab) vs oracle, {kind}", np.abs(out - orc).max() / _scale(orc), tol)
+        observe(f"eval_slab2 (one slab) vs oracle, {kind}", np.abs(out[:, sample] - orc).max() / _scale(orc), tol)
         ref = plain.evaluate(pts, list(w))
         assert plain.last_kernel() == "eval_mixed", plain.last_kernel()
         observe(f"eval_slab2 (one slab) vs eval_mixed, {kind}", np.abs(out - ref).max() / _scale(ref), 1e-5 if dt == np.float32 else 1e-13)
     nan = [p.copy() for p in pts]
-    nan[0][69_999] = np.nan
+    nan[0][n - 4] = np.nan
     nan[1][5] = np.nan
     out = t.evaluate(nan)
-    orc, _ = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], nan)      # (a variable of order 1 does not propagate its NaN)
-    assert np.array_equal(np.isnan(out), np.isnan(orc))
+    orc, _ = oracle.c_evaluate(order, ncoef, knots, coefs, [0, 0], [p[sample] for p in nan])      # (a variable of order 1 does not propagate its NaN)
+    assert np.array_equal(np.isnan(out[:, sample]), np.isnan(orc))
     assert np.isnan(out[:, 5]).all() or min(order) == 1
     ok = ~np.isnan(orc)
-    assert np.abs(out[ok] - orc[ok]).max() <= tol * _scale(orc[ok])
+    assert np.abs(out[:, sample][ok] - orc[ok]).max() <= tol * _scale(orc[ok])
     bad = [p.copy() for p in pts]
-    bad[0][70_002] = dt(9.0)
-    bad[1][66_000] = dt(-9.0)
+    bad[0][n - 1] = dt(9.0)
+    bad[1][1_066_000] = dt(-9.0)
     with pytest.raises(bspy_amd.DomainError) as e:
         t.evaluate(bad)
-    assert e.value.index == 66_000
+    assert e.value.index == 1_066_000
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
