@@ -7,7 +7,9 @@
 #include "bsk_slab.hpp"
 
 // Surfaces whose table can be streamed through LDS once per chunk of 8192 points (bsk_slab.hpp): no global sort.
-constexpr long long SLAB_MIN_POINTS = 1 << 16;
+// (tools/mixed_small.py on the TomsNasty shape: a launch takes 53 us for any batch up to 1.2 M points - every slab staged by every
+//  workgroup - against 14 - 34 us of the gather kernel up to 300 k points; even at 600 k: 54 against 65 us)
+constexpr long long SLAB_MIN_POINTS = 1 << 19;
 
 template <typename T, int O, bool MIXED>
 static bsk_status launch_eval_slab2(bsk_spline s, const Params<T> &prm, long long n, T *out, long long ostride, const Wrt &w,

@@ -569,7 +569,7 @@ def test_large_batches_in_cell_order(shape, monkeypatch):
     rng = np.random.default_rng(77)
     knots = [cases.nonuniform_knots(rng, o, c, dt, -1.0, 2.0) for o, c in zip(order, ncoef)]
     coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
-    n = 300_007
+    n = 600_007 if nind == 2 else 300_007                         # (surfaces: above eval_slab2's 2^19-point threshold)
     pts = [(-1.0 + 3.0 * rng.random(n)).astype(dt) for _ in range(nind)]
     # clustered points too: one cell takes most of the batch
     pts[0][: n // 2] = dt(0.123)
@@ -1211,14 +1211,14 @@ def test_mixed_order_surfaces_in_one_slab(order, ncoef, ndep, dt, monkeypatch):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_slab_kernel_rounds(dt, monkeypatch):
     """eval_slab2 orders up to 32 chunks of a workgroup per ROUND and starts another round after them - only batches beyond
-    67 M points reach a second round on 256 CUs.  BSK_SLAB_GRID = 1 makes one workgroup take all 37 chunks of a 300 k batch
-    (two rounds, the second with 5 chunks, the last chunk ragged), 3 gives 13 / 12 / 12: same bits as the full grid, for
-    evaluate and a derivative; offender index in the second round."""
+    67 M points reach a second round on 256 CUs.  BSK_SLAB_GRID = 1 makes one workgroup take all 65 chunks of a 530 k batch
+    (three rounds, the last with one ragged chunk), 3 gives 22 / 22 / 21: same bits as the full grid, for evaluate and a
+    derivative; offender index in the third round."""
     rng = np.random.default_rng(9)
     order, ncoef, ndep = (4, 5), (900 if dt == np.float64 else 1800, 11), 3      # the TomsNasty shape (238 KB: three passes); twice the rows in fp32
     knots = [cases.nonuniform_knots(rng, o, c, dt, 0.0, 1.0) for o, c in zip(order, ncoef)]
     coefs = rng.standard_normal((ndep, *ncoef)).astype(dt)
-    n = 300_017
+    n = 530_003
     pts = [rng.random(n).astype(dt) for _ in range(2)]
     t = DeviceSpline(order, ncoef, knots, coefs, dt)
     ref = [t.evaluate(pts), t.evaluate(pts, [1, 2])]
@@ -1232,11 +1232,11 @@ def test_slab_kernel_rounds(dt, monkeypatch):
         assert np.array_equal(t.evaluate(pts), ref[0]), grid
         assert np.array_equal(t.evaluate(pts, [1, 2]), ref[1]), grid
     bad = [p.copy() for p in pts]
-    bad[0][299_000] = dt(2.0)                                     # chunk 36: the second round of the only workgroup
+    bad[0][529_000] = dt(2.0)                                     # chunk 64: the third round of the only workgroup
     monkeypatch.setenv("BSK_SLAB_GRID", "1")
     with pytest.raises(bspy_amd.DomainError) as e:
         t.evaluate(bad)
-    assert e.value.index == 299_000
+    assert e.value.index == 529_000
 
 
 def _lut_steps(knots, order, ncoef):
@@ -1480,8 +1480,8 @@ def test_tessellate_more_patches_than_one_launch_takes():
 
 def test_random_large_tables_against_oracle():
     """Random L2-resident tables (nInd 1..3, equal or different orders <= 6, nDep 1..4, both dtypes):
-    the gather kernel on a small batch and the cell-order pipeline on a batch >= 2^18 points against
-    the C oracle."""
+    the gather kernel on a small batch, the cell-order pipeline on a batch >= 2^18 points and, for
+    surfaces, eval_slab2 on a batch >= 2^19 points against the C oracle."""
     trials = int(os.environ.get("BSK_SOAK_LARGE", "14"))        # BSK_SOAK_LARGE=80 for a longer sweep with another seed
     rng = np.random.default_rng(99 if trials == 14 else 4242)
     for trial in range(trials):
@@ -1500,7 +1500,7 @@ def test_random_large_tables_against_oracle():
         assert coefs.nbytes > 170_000
         t = DeviceSpline(order, ncoef, knots, coefs, dt)
         tol = 2e-5 if dt == np.float32 else 1e-12
-        for n in (4_097, 270_001):
+        for n in (4_097, 270_001) + ((530_003,) if nind == 2 else ()):       # surfaces: eval_slab2 from 2^19 points on
             pts = [rng.random(n).astype(dt) for _ in range(nind)]
             w = [int(rng.integers(0, 2)) for _ in range(nind)]
             idx = rng.choice(n, 4_000, replace=False)
